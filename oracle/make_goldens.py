@@ -1,0 +1,255 @@
+"""Generate the golden fixtures of tests/golden/ by running the REFERENCE itself on CPU.
+
+TEST INFRASTRUCTURE.  Runs only in the build container (``/root/reference`` does not exist on the
+GPU box); only the arrays it writes travel.  Usage::
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_goldens.py
+
+Import recipe: stub the off-path third-party modules the reference imports at
+file top level but never executes on this path (efficient_kan, lion_pytorch, gensim, pretty_midi,
+seaborn), re-export ``Tensor``/``math`` for ``from torch.nn.init import *`` users, chdir into the
+reference tree (its JSON tables are CWD-relative) and never write bytecode there.
+"""
+import builtins
+import math
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+
+from video2music_amd import synthetic                      # noqa: E402
+from video2music_amd.utilities import constants as C       # noqa: E402
+
+
+def import_reference():
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Absent:
+        def __init__(self, *a, **k):
+            raise RuntimeError("off-path third-party module is stubbed")
+
+    stub("efficient_kan", KANLinear=_Absent)
+    stub("lion_pytorch", Lion=_Absent)
+    g = stub("gensim")
+    g.models = stub("gensim.models", Word2Vec=_Absent)
+    stub("pretty_midi", Note=_Absent, PrettyMIDI=_Absent, Instrument=_Absent, ControlChange=_Absent)
+    stub("seaborn")
+    builtins.Tensor = torch.Tensor
+    builtins.math = math
+    sys.path.insert(0, REF)
+    os.chdir(REF)
+    sys.argv = [sys.argv[0]]
+    import model.video_music_transformer as vmt
+    import model.grouped_query_attention as gqa
+    import model.moe as moe
+    import model.custom_transformer as ct
+    import model.rotate_operation as ro
+    import model.rpr as rpr
+    import model.positional_encoding as pe
+    import third_party.log_maxvio as lm
+    lm.change_maxvio_logging_state(False)
+    return types.SimpleNamespace(vmt=vmt, gqa=gqa, moe=moe, ct=ct, ro=ro, rpr=rpr, pe=pe)
+
+
+def load_synthetic(module, seed=0):
+    shapes = [(k, tuple(v.shape)) for k, v in module.state_dict().items()]
+    sd = synthetic.synthetic_state_dict(shapes, seed=seed)
+    module.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    return sd
+
+
+def t(x):
+    return torch.from_numpy(np.asarray(x))
+
+
+def check_tables():
+    import json
+    inv = json.load(open(os.path.join(REF, "dataset/vevo_meta/chord_inv.json")))
+    fwd = json.load(open(os.path.join(REF, "dataset/vevo_meta/chord.json")))
+    root = json.load(open(os.path.join(REF, "dataset/vevo_meta/chord_root.json")))
+    attr = json.load(open(os.path.join(REF, "dataset/vevo_meta/chord_attr.json")))
+    assert inv == C.CHORD_INV_DIC, "chord_inv.json differs"
+    assert fwd == C.CHORD_DIC, "chord.json differs"
+    assert root == C.CHORD_ROOT_DIC, "chord_root.json differs"
+    assert attr == C.CHORD_ATTR_DIC, "chord_attr.json differs"
+    # the id -> (root, attr) rule generate() applies through the JSON tables
+    ra = np.zeros((C.CHORD_END, 2), dtype=np.int64)
+    for i in range(C.CHORD_END):
+        parts = inv[str(i)].split(":")
+        ra[i] = (root[parts[0]], 1 if len(parts) == 1 else attr[parts[1]])
+        assert tuple(ra[i]) == C.chord_to_root_attr(i)
+    return ra
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = import_reference()
+    torch.manual_seed(0)
+    torch.set_grad_enabled(False)
+
+    # ---------------- G0: known-answer pieces ----------------
+    root_attr = check_tables()
+    skew_in = torch.arange(16, dtype=torch.float32).reshape(1, 4, 4)
+    skew_out = ref.rpr._skew(skew_in)
+    rs = np.random.RandomState(7)
+    skew_rand_in = rs.standard_normal((3, 9, 9)).astype(np.float32)
+    pe128 = ref.pe.PositionalEncoding(128, 0.0, 300).pe[:, 0, :]
+    pe512 = ref.pe.PositionalEncoding(512, 0.0, 1024).pe[:, 0, :]
+    np.savez_compressed(os.path.join(OUT, "g0_kat.npz"),
+                        chord_root_attr=root_attr,
+                        skew_in=skew_in.numpy(), skew_out=skew_out.numpy(),
+                        skew_rand_in=skew_rand_in, skew_rand_out=ref.rpr._skew(t(skew_rand_in)).numpy(),
+                        pe128_rows=pe128[[0, 1, 2, 3, 150, 299]].numpy(),
+                        pe512_rows=pe512[[0, 1, 2, 3, 511, 1023]].numpy())
+
+    # ---------------- config-1 model: 2 layers, d=128, H=4, dff=256 ----------------
+    cfg = dict(n_layers=2, num_heads=4, d_model=128, dim_feedforward=256, max_sequence_chord=300,
+               total_vf_dim=synthetic.total_vf_dim(1), rpr=True)
+    model = ref.vmt.VideoMusicTransformer(**cfg).eval()
+    load_synthetic(model, seed=0)
+    feats = synthetic.synthetic_features(3, seed=1234)
+    key = np.array([[0.0], [1.0], [0.0]], dtype=np.float32)
+
+    def fwd(rootv, attrv, b):
+        sl = slice(0, b)
+        x = torch.zeros_like(t(rootv))
+        return model(x, t(rootv), t(attrv), t(feats["semantic"][sl]), t(key[sl]),
+                     t(feats["scene_offset"][sl]), t(feats["motion"][sl]), t(feats["emotion"][sl]))
+
+    out = {}
+    rs = np.random.RandomState(11)
+    for B in (1, 3):
+        for L in (1, 12, 64):
+            rootv = rs.randint(0, 13, size=(B, L)).astype(np.int64)
+            attrv = rs.randint(0, 14, size=(B, L)).astype(np.int64)
+            # a few PAD positions as generate(beam=1) feeds them
+            if L > 4:
+                rootv[:, -2:] = C.CHORD_ROOT_PAD
+                attrv[:, -2:] = C.CHORD_ATTR_PAD
+            out[f"root_B{B}_L{L}"] = rootv
+            out[f"attr_B{B}_L{L}"] = attrv
+            out[f"logits_B{B}_L{L}"] = fwd(rootv, attrv, B).numpy()
+    # per-layer decoder activations for B=3, L=12 (hooks on the reference's decoder layers)
+    acts = []
+    hooks = [l.register_forward_hook(lambda m, i, o: acts.append(o.permute(1, 0, 2).contiguous().numpy()))
+             for l in model.transformer.decoder.layers]
+    enc = []
+    hooks.append(model.transformer.encoder.register_forward_hook(
+        lambda m, i, o: enc.append(o.permute(1, 0, 2).contiguous().numpy())))
+    fwd(out["root_B3_L12"], out["attr_B3_L12"], 3)
+    for h in hooks:
+        h.remove()
+    for i, a in enumerate(acts):
+        out[f"dec_layer{i}_B3_L12"] = a
+    out["memory_B3"] = enc[0]
+    out["key"] = key
+    np.savez_compressed(os.path.join(OUT, "g_fwd_cfg1.npz"), **out)
+
+    # ---------------- G1 / G2 generate, T=64, clip 0 and clip 1 ----------------
+    gen = {}
+    Categorical = torch.distributions.categorical.Categorical
+    orig_sample = Categorical.sample
+    for clip, (pr, prr, pra) in ((0, C.primer_from_name("C")), (1, C.primer_from_name("A:min"))):
+        sl = slice(clip, clip + 1)
+        kw = dict(feature_semantic_list=t(feats["semantic"][sl]), feature_key=t(key[clip]),
+                  feature_scene_offset=t(feats["scene_offset"][sl]), feature_motion=t(feats["motion"][sl]),
+                  feature_emotion=t(feats["emotion"][sl]),
+                  primer=torch.tensor([pr]), primer_root=torch.tensor([prr]), primer_attr=torch.tensor([pra]),
+                  target_seq_length=64)
+        g1 = model.generate(beam=1, beam_chance=1.0, **kw)
+        margins = []
+
+        def argmax_sample(self, sample_shape=torch.Size()):
+            top2 = torch.topk(self.probs.flatten(), 2)[0]
+            margins.append(float(top2[0] - top2[1]))
+            return self.probs.argmax(-1)
+
+        Categorical.sample = argmax_sample
+        try:
+            g2 = model.generate(beam=0, **kw)
+            g2_nosup = model.generate(beam=0, max_conseq_N=1, max_conseq_chord=3, **kw)
+        finally:
+            Categorical.sample = orig_sample
+        gen[f"g1_clip{clip}"] = g1.numpy()
+        gen[f"g2_clip{clip}"] = g2.numpy()
+        gen[f"g2_margins_clip{clip}"] = np.array(margins[:63], dtype=np.float64)
+        gen[f"g2_N1_c3_clip{clip}"] = g2_nosup.numpy()
+        gen[f"primer_clip{clip}"] = np.array([pr, prr, pra], dtype=np.int64)
+        print("clip", clip, "G1 unique", len(set(g1.flatten().tolist())), "G2 unique", len(set(g2.flatten().tolist())),
+              "min margin", min(margins[:63]))
+    np.savez_compressed(os.path.join(OUT, "g_gen_cfg1.npz"), **gen)
+
+    # ---------------- G-gqa ----------------
+    gq = {}
+    m = ref.gqa.MultiheadGQA(128, 8, 2).eval()
+    load_synthetic(m, seed=3)
+    rs = np.random.RandomState(21)
+    for L, B in ((6, 1), (6, 3), (64, 1), (64, 3)):
+        x = rs.standard_normal((L, B, 128)).astype(np.float32)
+        gq[f"x_L{L}_B{B}"] = x
+        for causal in (False, True):
+            y, _ = m(t(x), t(x), t(x), is_causal=causal)
+            gq[f"y_L{L}_B{B}_c{int(causal)}"] = y.numpy()
+    np.savez_compressed(os.path.join(OUT, "g_gqa.npz"), **gq)
+
+    # ---------------- G-moe ----------------
+    mo = {}
+    rs = np.random.RandomState(31)
+    x = rs.standard_normal((16, 3, 128)).astype(np.float32)
+    mo["x"] = x
+    sel = []
+    topk_orig = torch.topk
+    for name, layer in (("moe", ref.moe.MoELayer(ref.moe.GLUExpert(128, 256), 128, n_experts=8, n_experts_per_token=2)),
+                        ("shared", ref.moe.SharedMoELayer(ref.moe.GLUExpert(128, 256), 128, n_experts=8,
+                                                          n_experts_per_token=2, balancing=True))):
+        layer.eval()
+        load_synthetic(layer, seed=5)       # per-expert names -> distinct expert weights
+        y = layer(t(x))
+        logits = layer.gate(t(x))
+        w, idx = topk_orig(logits, 2)
+        mo[f"y_{name}"] = y.numpy()
+        mo[f"idx_{name}"] = idx.numpy()
+        mo[f"w_{name}"] = torch.softmax(w.float(), -1).numpy()
+    np.savez_compressed(os.path.join(OUT, "g_moe.npz"), **mo)
+
+    # ---------------- G-rms / G-rope ----------------
+    rr = {}
+    rs = np.random.RandomState(41)
+    x = rs.standard_normal((5, 3, 128)).astype(np.float32)
+    rms = ref.ct.RMSNorm(128)
+    rms.weight.data = t(synthetic.fill_tensor("norm.weight", (128,), 9))
+    rr["rms_x"] = x
+    rr["rms_w"] = rms.weight.data.numpy()
+    rr["rms_y"] = rms(t(x)).numpy()
+    H, hd = 4, 32
+    ropem = ref.ro.RotaryPositionalEmbeddings(128, 300)
+    for B in (1, 2):
+        L = 10
+        q = rs.standard_normal((L, B, 128)).astype(np.float32)       # projected (L,B,E) as custom_transformer.py:1044
+        qv = t(q).view(H, L, B, hd)
+        y = ropem.forward(qv).view(L, B, 128)
+        rr[f"rope_x_B{B}"] = q
+        rr[f"rope_y_B{B}"] = y.numpy()
+    # head-dim sized cache, plain (b, s, n_h, h_d) use as documented in rotate_operation.py:111-130
+    rope_hd = ref.ro.RotaryPositionalEmbeddings(32, 64)
+    xh = rs.standard_normal((2, 12, 4, 32)).astype(np.float32)
+    rr["rope_hd_x"] = xh
+    rr["rope_hd_y"] = rope_hd.forward(t(xh)).numpy()
+    np.savez_compressed(os.path.join(OUT, "g_rms_rope.npz"), **rr)
+    print("goldens written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

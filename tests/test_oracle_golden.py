@@ -1,0 +1,128 @@
+"""The CPU oracle (oracle/amt_oracle.py) against goldens produced by the reference itself
+(oracle/make_goldens.py).  Runs without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import amt_oracle as O
+from video2music_amd import synthetic
+from video2music_amd.utilities import constants as C
+from helpers import CFG1, synthetic_sd, feats_t
+
+TOL = 2e-5   # oracle vs reference logits (same fp32 arithmetic, different op grouping)
+
+
+def test_kat_skew_pe_tables(golden):
+    g = golden("g0_kat.npz")
+    assert np.array_equal(O.skew(torch.from_numpy(g["skew_in"])).numpy(), g["skew_out"])
+    assert g["skew_out"][0].tolist() == [[3, 0, 0, 0], [6, 7, 0, 0], [9, 10, 11, 0], [12, 13, 14, 15]]
+    assert np.array_equal(O.skew(torch.from_numpy(g["skew_rand_in"])).numpy(), g["skew_rand_out"])
+    pe = O.positional_encoding(300, 128)
+    assert np.array_equal(pe[[0, 1, 2, 3, 150, 299]].numpy(), g["pe128_rows"])
+    pe = O.positional_encoding(1024, 512)
+    assert np.array_equal(pe[[0, 1, 2, 3, 511, 1023]].numpy(), g["pe512_rows"])
+    for i in range(C.CHORD_END):
+        assert tuple(g["chord_root_attr"][i]) == C.chord_to_root_attr(i) == O.root_attr_of(i)
+
+
+def test_skew_equals_closed_form():
+    rs = np.random.RandomState(0)
+    q = torch.from_numpy(rs.standard_normal((2, 3, 17, 8)).astype(np.float32))
+    Er = torch.from_numpy(rs.uniform(size=(40, 8)).astype(np.float32))
+    qe = torch.einsum("bhld,md->bhlm", q, Er[40 - 17:])
+    a = O.skew(qe)
+    b = O.rpr_bias_closed_form(q, Er)
+    tri = torch.tril(torch.ones(17, 17, dtype=torch.bool))
+    assert torch.allclose(a[..., tri], b[..., tri], atol=1e-6)
+
+
+@pytest.mark.parametrize("B,L", [(1, 1), (1, 12), (1, 64), (3, 1), (3, 12), (3, 64)])
+def test_forward_logits(golden, B, L):
+    g = golden("g_fwd_cfg1.npz")
+    sd = synthetic_sd(CFG1)
+    f = feats_t(synthetic.synthetic_features(3, seed=1234), slice(0, B), key=g["key"])
+    logits = O.forward(sd, CFG1["num_heads"], torch.from_numpy(g[f"root_B{B}_L{L}"]), torch.from_numpy(g[f"attr_B{B}_L{L}"]),
+                       f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"])
+    assert logits.shape == (B, L, 159)
+    assert np.abs(logits.numpy() - g[f"logits_B{B}_L{L}"]).max() < TOL
+
+
+def test_forward_layer_activations(golden):
+    g = golden("g_fwd_cfg1.npz")
+    sd = synthetic_sd(CFG1)
+    f = feats_t(synthetic.synthetic_features(3, seed=1234), key=g["key"])
+    mem = O.encode(sd, 4, f["semantic"], f["scene_offset"], f["motion"], f["emotion"])
+    assert np.abs(mem.numpy() - g["memory_B3"]).max() < TOL
+    acts = []
+    O.forward(sd, 4, torch.from_numpy(g["root_B3_L12"]), torch.from_numpy(g["attr_B3_L12"]),
+              f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], collect=acts)
+    for i, a in enumerate(acts):
+        assert np.abs(a.numpy() - g[f"dec_layer{i}_B3_L12"]).max() < TOL
+
+
+@pytest.mark.parametrize("clip", [0, 1])
+def test_generate_g1_g2(golden, clip):
+    g = golden("g_gen_cfg1.npz")
+    key = golden("g_fwd_cfg1.npz")["key"]
+    sd = synthetic_sd(CFG1)
+    f = feats_t(synthetic.synthetic_features(3, seed=1234), slice(clip, clip + 1), key=key)
+    pr, prr, pra = (torch.tensor([int(v)]) for v in g[f"primer_clip{clip}"])
+    args = (sd, 4, f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], pr, prr, pra)
+    g1 = O.generate(*args, target_seq_length=64, beam=1)
+    assert np.array_equal(g1.numpy(), g[f"g1_clip{clip}"])
+    margins = []
+    g2 = O.generate(*args, target_seq_length=64, beam=0, margins=margins)
+    assert np.array_equal(g2.numpy(), g[f"g2_clip{clip}"])
+    assert np.abs(np.array(margins) - g[f"g2_margins_clip{clip}"]).max() < 1e-4
+    assert min(margins) > 1e-2          # the arg-max decisions of the fixture are well conditioned
+    g2b = O.generate(*args, target_seq_length=64, beam=0, max_conseq_N=1, max_conseq_chord=3)
+    assert np.array_equal(g2b.numpy(), g[f"g2_N1_c3_clip{clip}"])
+
+
+@pytest.mark.parametrize("L,B", [(6, 1), (6, 3), (64, 1), (64, 3)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_gqa(golden, L, B, causal):
+    g = golden("g_gqa.npz")
+    shapes = [("q_proj.weight", (128, 128)), ("q_proj.bias", (128,)), ("k_proj.weight", (32, 128)), ("k_proj.bias", (32,)),
+              ("v_proj.weight", (32, 128)), ("v_proj.bias", (32,)), ("norm.weight", (128,)), ("norm.bias", (128,)),
+              ("out_proj.weight", (128, 128)), ("out_proj.bias", (128,))]
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=3).items()}
+    x = torch.from_numpy(g[f"x_L{L}_B{B}"])
+    y = O.gqa_forward(x, x, x, sd, 8, 2, is_causal=causal)
+    assert np.abs(y.numpy() - g[f"y_L{L}_B{B}_c{int(causal)}"]).max() < TOL
+
+
+def moe_shapes(n_exp, d, dff, shared):
+    out = [("gate.weight", (n_exp, d)), ("gate.bias", (n_exp,))]
+    names = [f"experts.{e}." for e in range(n_exp)] + (["shared_expert."] if shared else [])
+    for p in names:
+        out += [(p + "linear1.weight", (dff, d)), (p + "linear1.bias", (dff,)),
+                (p + "linear2.weight", (d, dff)), (p + "linear2.bias", (d,)),
+                (p + "gate.weight", (dff, d)), (p + "gate.bias", (dff,))]
+    return out
+
+
+@pytest.mark.parametrize("name", ["moe", "shared"])
+def test_moe(golden, name):
+    g = golden("g_moe.npz")
+    shared = name == "shared"
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(moe_shapes(8, 128, 256, shared), seed=5).items()}
+    routing = {}
+    y = O.moe_forward(torch.from_numpy(g["x"]), sd, 8, k=2, shared=shared, routing=routing)
+    assert np.array_equal(routing["idx"].numpy(), g[f"idx_{name}"])
+    assert np.abs(routing["weights"].numpy() - g[f"w_{name}"]).max() < 1e-6
+    assert np.abs(y.numpy() - g[f"y_{name}"]).max() < TOL
+
+
+def test_rms_rope(golden):
+    g = golden("g_rms_rope.npz")
+    y = O.rms_norm(torch.from_numpy(g["rms_x"]), torch.from_numpy(g["rms_w"]))
+    assert np.abs(y.numpy() - g["rms_y"]).max() < 1e-6
+    cache = O.rope_cache(128, 300)
+    for B in (1, 2):
+        x = torch.from_numpy(g[f"rope_x_B{B}"])
+        L = x.shape[0]
+        y = O.rope(x.view(4, L, B, 32), cache).reshape(L, B, 128)
+        assert np.abs(y.numpy() - g[f"rope_y_B{B}"]).max() < 1e-6
+    y = O.rope(torch.from_numpy(g["rope_hd_x"]), O.rope_cache(32, 64))
+    assert np.abs(y.numpy() - g["rope_hd_y"]).max() < 1e-6
