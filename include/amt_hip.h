@@ -1,0 +1,158 @@
+/*
+ * libamt_hip — C ABI of the MI355X (gfx950) implementation of the Affective Multimodal Transformer
+ * forward / generate hot path of khangklj/Video2Music.
+ *
+ * The reference has no FFI of its own: its seam for this path is the Python nn.Module surface
+ *   model/video_music_transformer.py:910-1132   class VideoMusicTransformer (forward, generate)
+ *   model/rpr.py:17-455                         TransformerDecoderRPR / MultiheadAttentionRPR / _skew
+ *   model/positional_encoding.py:7-23           PositionalEncoding
+ *   model/grouped_query_attention.py:172-358    MultiheadGQA
+ *   model/moe.py:36-49,150-302                  GLUExpert / MoELayer / SharedMoELayer
+ *   model/custom_transformer.py:27-48           RMSNorm
+ *   model/rotate_operation.py:50-165            RotaryPositionalEmbeddings
+ * Each entry point below names the reference code it replaces.  The Python host module
+ * (video2music_amd/model/ python files) binds these with ctypes; INTEGRATION.md shows the stub a maintainer
+ * of the reference would add.
+ *
+ * Conventions
+ *   - every function returns int32: 0 = ok, < 0 = bad argument, > 0 = hipError_t;
+ *     amt_last_error() returns a thread-local message for the last non-zero return.
+ *   - all tensor arguments are raw DEVICE pointers, fp32 (ids int64), row-major, 16-byte aligned;
+ *     the caller owns inputs and outputs; weights are copied (and repacked) into library-owned
+ *     memory by amt_load_weight, so caller storage may be freed afterwards.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     nothing synchronises the device except amt_finalize / amt_destroy.  amt_generate captures
+ *     its decode step into a hipGraph on first use for a given (batch, mode).
+ *   - one handle per (process, device); a handle is not thread-safe.
+ */
+#ifndef AMT_HIP_H
+#define AMT_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct amt_handle amt_handle;
+
+/* Constructor arguments of VideoMusicTransformer (model/video_music_transformer.py:911-914) that
+ * shape the computation, plus the batch capacity the reference does not have (it is batch-1). */
+typedef struct amt_config {
+    int32_t n_layers;            /* encoder and decoder layers (6) */
+    int32_t num_heads;           /* 8 */
+    int32_t d_model;             /* 512 */
+    int32_t dim_feedforward;     /* 1024 */
+    int32_t max_sequence_video;  /* 300: rows of positional_encoding_video.pe, key capacity of cross-attention */
+    int32_t max_sequence_chord;  /* rows of Er / positional_encoding.pe = longest chord sequence */
+    int32_t total_vf_dim;        /* width of the concatenated video feature (generate.py:141-160) */
+    int32_t max_batch;           /* clips per call (<= 32 per decode batch) */
+} amt_config;
+
+const char* amt_last_error(void);
+int32_t amt_abi_version(void);
+
+/* ---- model lifetime -------------------------------------------------------------------- */
+int32_t amt_create(const amt_config* cfg, amt_handle** out);
+int32_t amt_destroy(amt_handle* h);
+/* One state_dict entry (reference key names).  `data` may be a host or a
+ * device pointer; `shape` has `ndim` entries.  Replaces nn.Module.load_state_dict (generate.py:216). */
+int32_t amt_load_weight(amt_handle* h, const char* name, const float* data, int32_t ndim, const int64_t* shape);
+/* Validates that every tensor of the hot path is present with the right shape and builds the
+ * derived layouts (MFMA-ordered decode weights, Linear_chord tables).  Synchronises the device. */
+int32_t amt_finalize(amt_handle* h);
+
+/* ---- VideoMusicTransformer.forward pieces ------------------------------------------------ */
+/* Video stream + encoder + per-layer cross-attention K/V (video_music_transformer.py:1005-1033,
+ * torch nn.TransformerEncoder).  sem (B,S,sem_dim), scene (B,S), motion (B,S,motion_dim) with
+ * motion_dim=1 for the scalar form, emotion (B,S,emo_dim).  Optionally copies the encoder memory
+ * (B,S,d) to memory_out.  The handle keeps memory / K / V for amt_prefill and amt_generate. */
+int32_t amt_encode(amt_handle* h, int32_t B, int32_t S,
+                   const float* sem, int32_t sem_dim, const float* scene,
+                   const float* motion, int32_t motion_dim, const float* emotion, int32_t emo_dim,
+                   float* memory_out, void* stream);
+/* Teacher-forced decoder pass (video_music_transformer.py:984-1001,1027-1044; rpr.py:24-70) over
+ * the clips of the last amt_encode: root/attr ids (B,L) int64, key (B) -> logits (B,L,159).
+ * layer_out (optional) receives the output of decoder layer `layer_index` (B,L,d). */
+int32_t amt_prefill(amt_handle* h, int32_t B, int32_t L, const int64_t* root_ids, const int64_t* attr_ids,
+                    const float* key, float* logits_out, float* layer_out, int32_t layer_index, void* stream);
+
+/* ---- VideoMusicTransformer.generate (video_music_transformer.py:1046-1132), batched ------ */
+/* Starts a generation over the B clips of the last amt_encode.  primer* are (B,P) int64 when
+ * primer_per_clip != 0, else (P) shared by all clips.  beam: 0 = sampling branch, 1 = verbatim
+ * top-1 branch.  Resets the KV cache and the device position counter. */
+int32_t amt_generate_begin(amt_handle* h, int32_t B, const int64_t* primer, const int64_t* primer_root,
+                           const int64_t* primer_attr, int32_t P, int32_t primer_per_clip, const float* key,
+                           int32_t T, int32_t beam, int32_t max_conseq_N, int32_t max_conseq_chord, void* stream);
+/* Runs `n_steps` decode steps with the arg-max sampler on device (hipGraph replay; oracle G2 for
+ * beam=0, G1 for beam=1).  logits_out (optional) is (T,B,159): row t = logits computed from input
+ * position t.  n_steps < 0 runs to the end (T-1 steps in total). */
+int32_t amt_generate_run(amt_handle* h, int32_t n_steps, float* logits_out, void* stream);
+/* One decode step that stops before the decision: writes the decision distribution
+ * softmax(logits)[:157] with the suppressions applied, (B,157), for a host-side sampler
+ * (torch.multinomial = the reference's Categorical.sample), then amt_generate_commit feeds the
+ * chosen ids (B) int64 back. */
+int32_t amt_generate_step_probs(amt_handle* h, float* probs_out, void* stream);
+int32_t amt_generate_commit(amt_handle* h, const int64_t* chosen, void* stream);
+/* Copies the (B,T) int64 token matrix (PAD=158 beyond the generated length) to tokens_out. */
+int32_t amt_generate_end(amt_handle* h, int64_t* tokens_out, void* stream);
+/* begin + run(-1) + end. */
+int32_t amt_generate(amt_handle* h, int32_t B, const int64_t* primer, const int64_t* primer_root,
+                     const int64_t* primer_attr, int32_t P, int32_t primer_per_clip, const float* key,
+                     int32_t T, int32_t beam, int32_t max_conseq_N, int32_t max_conseq_chord,
+                     int64_t* tokens_out, float* logits_out, void* stream);
+/* Timing/roofline introspection for bench.py: algorithmic HBM bytes of the decode-attention
+ * launches of one step at key count n_keys (self) — see DESIGN.md. */
+int64_t amt_decode_step_bytes(const amt_handle* h, int32_t B, int32_t n_self_keys, int32_t S);
+
+/* ---- stateless operator entry points (used by the parity tests and standalone modules) --- */
+/* y[M,N] = x[M,K] . w[N,K]^T + bias (+ resid) ; optional ReLU.  torch.nn.functional.linear. K % 32 == 0. */
+int32_t amt_linear_fwd(const float* x, const float* w, const float* bias, const float* resid, float* y,
+                       int32_t M, int32_t N, int32_t K, int32_t relu, void* stream);
+/* y = LayerNorm(x (+ resid)) (torch.nn.LayerNorm; rpr.py:59-69). */
+int32_t amt_layernorm_fwd(const float* x, const float* resid, const float* w, const float* b, float* y,
+                          int32_t rows, int32_t dim, float eps, void* stream);
+/* RMSNorm.forward (custom_transformer.py:38-45); w may be null. */
+int32_t amt_rmsnorm_fwd(const float* x, const float* w, float* y, int32_t rows, int32_t dim, float eps, void* stream);
+/* RotaryPositionalEmbeddings.forward (rotate_operation.py:111-165), input_pos=None: x is
+ * (n0, seq, n2, hd); cache is the module's (max_seq, cache_half, 2) buffer. */
+int32_t amt_rope_fwd(const float* x, const float* cache, float* y, int32_t n0, int32_t seq, int32_t n2, int32_t hd,
+                     int32_t cache_half, void* stream);
+/* Core of multi_head_attention_forward_rpr (rpr.py:387-414) after the projections: q (already
+ * scaled), k, v are (B,L,H*hd) row-major; Er (er_len,hd); causal.  o (B,L,H*hd). */
+int32_t amt_rpr_attn_fwd(const float* q, const float* k, const float* v, const float* Er, float* o,
+                         int32_t B, int32_t H, int32_t L, int32_t hd, int32_t er_len, void* stream);
+/* Core of torch MultiheadAttention as used at rpr.py:62-63 / the video encoder: q (B,Lq,H*hd)
+ * scaled, k,v (B,Lk,H*hd); no mask (causal=0) or causal. */
+int32_t amt_cross_attn_fwd(const float* q, const float* k, const float* v, float* o,
+                           int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd, int32_t causal, void* stream);
+/* Decode-step forms: q (B,H*hd) for the token at position pos (host value), K/V caches
+ * (B,H,cap,hd); keys 0..pos.  Er may be null (cross-attention: pass pos = S-1). */
+int32_t amt_attn_decode_fwd(const float* q, const float* kcache, const float* vcache, const float* Er, float* o,
+                            int32_t B, int32_t H, int32_t hd, int32_t cap, int32_t pos, int32_t er_len, void* stream);
+/* Decode-step projection: y[B,N] = LN?(x)[B,K] . w[N,K]^T + bias (+resid)(relu); packs w on the fly
+ * into `w_packed_scratch` (N_pad16*K floats).  ln_w/ln_b may be null.  B <= 32, K % 64 == 0. */
+int32_t amt_decode_linear_fwd(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b,
+                              const float* resid, float* y, float* xn_out, float* w_packed_scratch,
+                              int32_t B, int32_t N, int32_t K, int32_t relu, float eps, void* stream);
+/* MultiheadGQA.forward (grouped_query_attention.py:286-358) without RoPE: query/key/value are the
+ * caller's (L,B,E) buffers, weights in nn.Linear layout; scratch >= 4*L*B*E floats. */
+int32_t amt_gqa_fwd(const float* query, const float* key, const float* value,
+                    const float* wq, const float* bq, const float* wk, const float* bk, const float* wv, const float* bv,
+                    const float* ln_w, const float* ln_b, const float* wo, const float* bo,
+                    float* out, float* scratch, int32_t L, int32_t S, int32_t B, int32_t E, int32_t query_heads,
+                    int32_t kv_heads, int32_t is_causal, float ln_eps, void* stream);
+/* MoELayer.forward / SharedMoELayer.forward, eval mode (moe.py:167-200,231-302): x (n_tok,d);
+ * gate (n_exp,d)+(n_exp); experts' linear1/gate (n_exp,dff,d)+(n_exp,dff), linear2 (n_exp,d,dff)+(n_exp,d);
+ * shared_* may be null.  top-k = 2.  idx_out/w_out (optional) receive the routing (n_tok,2).
+ * scratch: see amt_moe_scratch_floats. */
+int64_t amt_moe_scratch_floats(int32_t n_tok, int32_t d, int32_t dff, int32_t n_exp);
+int32_t amt_moe_fwd(const float* x, const float* gate_w, const float* gate_b,
+                    const float* w1, const float* b1, const float* wg, const float* bg, const float* w2, const float* b2,
+                    const float* sw1, const float* sb1, const float* swg, const float* sbg, const float* sw2, const float* sb2,
+                    float* out, int32_t* idx_out, float* w_out, float* scratch,
+                    int32_t n_tok, int32_t d, int32_t dff, int32_t n_exp, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMT_HIP_H */

@@ -1,0 +1,184 @@
+"""Per-operator parity: HIP kernels through the C ABI vs the CPU oracle, same seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import amt_oracle as O
+from video2music_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(x):
+    return torch.as_tensor(x).cuda().contiguous()
+
+
+def sp():
+    return _lib.stream_ptr()
+
+
+def rnd(rs, *shape, scale=1.0):
+    return torch.from_numpy((rs.standard_normal(shape) * scale).astype(np.float32))
+
+
+@pytest.mark.parametrize("M,N,K,relu,resid", [(128, 128, 32, 0, False), (300, 159, 512, 0, False), (1000, 1536, 128, 1, True),
+                                             (15, 512, 512, 0, False), (257, 130, 1312, 0, True)])
+def test_linear(M, N, K, relu, resid):
+    rs = np.random.RandomState(M + N)
+    x, w, b = rnd(rs, M, K), rnd(rs, N, K, scale=K ** -0.5), rnd(rs, N)
+    r = rnd(rs, M, N) if resid else None
+    ref = O.linear(x.double(), w.double(), b.double())
+    if resid:
+        ref = ref + r.double()
+    if relu:
+        ref = torch.relu(ref)
+    y = torch.empty(M, N, device="cuda")
+    dx, dw, db, dr = dev(x), dev(w), dev(b), dev(r) if resid else None
+    _lib.call("amt_linear_fwd", _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(dr), _lib.ptr(y), M, N, K, relu, sp())
+    assert (y.cpu().double() - ref).abs().max() < 2e-5      # fp32 fma chain vs fp64
+
+
+@pytest.mark.parametrize("rows,dim", [(1, 128), (7, 512), (1000, 512), (33, 1024)])
+def test_layernorm_rmsnorm(rows, dim):
+    rs = np.random.RandomState(rows)
+    x, r, w, b = rnd(rs, rows, dim, scale=3.0), rnd(rs, rows, dim), rnd(rs, dim), rnd(rs, dim)
+    y = torch.empty(rows, dim, device="cuda")
+    dx, dr, dw, db = dev(x), dev(r), dev(w), dev(b)
+    _lib.call("amt_layernorm_fwd", _lib.ptr(dx), _lib.ptr(dr), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(y), rows, dim, 1e-5, sp())
+    assert (y.cpu() - O.layer_norm(x + r, w, b)).abs().max() < 2e-5
+    _lib.call("amt_layernorm_fwd", _lib.ptr(dx), None, _lib.ptr(dw), _lib.ptr(db), _lib.ptr(y), rows, dim, 1e-5, sp())
+    assert (y.cpu() - O.layer_norm(x, w, b)).abs().max() < 2e-5
+    _lib.call("amt_rmsnorm_fwd", _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(y), rows, dim, 1e-6, sp())
+    assert (y.cpu() - O.rms_norm(x, w)).abs().max() < 2e-5
+
+
+def test_rmsnorm_rope_golden(golden):
+    g = golden("g_rms_rope.npz")
+    x, w = dev(g["rms_x"]), dev(g["rms_w"])
+    y = torch.empty_like(x)
+    _lib.call("amt_rmsnorm_fwd", _lib.ptr(x), _lib.ptr(w), _lib.ptr(y), x.shape[0] * x.shape[1], x.shape[2], 1e-6, sp())
+    assert np.abs(y.cpu().numpy() - g["rms_y"]).max() < 1e-5
+    cache = dev(O.rope_cache(128, 300))
+    for B in (1, 2):                     # the (H,L,B,hd) view of custom_transformer.py:1044-1053 with a dim=d_model cache
+        x = dev(g[f"rope_x_B{B}"])
+        L = x.shape[0]
+        y = torch.empty_like(x)
+        _lib.call("amt_rope_fwd", _lib.ptr(x), _lib.ptr(cache), _lib.ptr(y), 4, L, B, 32, 64, sp())
+        assert np.abs(y.cpu().numpy() - g[f"rope_y_B{B}"]).max() < 1e-5
+    x = dev(g["rope_hd_x"])              # documented (b, s, n_h, h_d) use with a head-dim cache
+    y = torch.empty_like(x)
+    c2 = dev(O.rope_cache(32, 64))
+    _lib.call("amt_rope_fwd", _lib.ptr(x), _lib.ptr(c2), _lib.ptr(y), 2, 12, 4, 32, 16, sp())
+    assert np.abs(y.cpu().numpy() - g["rope_hd_y"]).max() < 1e-5
+
+
+def ref_rpr_attn(q, k, v, Er, H):
+    qh, kh, vh = O.split_heads(q, H), O.split_heads(k, H), O.split_heads(v, H)
+    L = q.shape[1]
+    s = qh @ kh.transpose(-1, -2)
+    qe = torch.einsum("bhld,md->bhlm", qh, Er[Er.shape[0] - L:])
+    s = s + O.skew(qe) + torch.triu(torch.full((L, L), float("-inf"), dtype=q.dtype), diagonal=1)
+    return O.merge_heads(torch.softmax(s, -1) @ vh)
+
+
+@pytest.mark.parametrize("B,H,L,hd,er_len", [(1, 4, 1, 32, 300), (2, 4, 12, 32, 300), (3, 4, 64, 32, 300), (2, 8, 129, 64, 200),
+                                            (1, 8, 300, 64, 300), (2, 2, 257, 64, 1024), (1, 2, 70, 128, 128)])
+def test_rpr_attention_prefill(B, H, L, hd, er_len):
+    rs = np.random.RandomState(L)
+    E = H * hd
+    q, k, v = rnd(rs, B, L, E, scale=0.5), rnd(rs, B, L, E), rnd(rs, B, L, E)
+    Er = torch.from_numpy(rs.uniform(size=(er_len, hd)).astype(np.float32))
+    ref = ref_rpr_attn(q.double(), k.double(), v.double(), Er.double(), H)
+    o = torch.empty(B, L, E, device="cuda")
+    dq, dk, dv, de = dev(q), dev(k), dev(v), dev(Er)
+    _lib.call("amt_rpr_attn_fwd", _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(de), _lib.ptr(o), B, H, L, hd, er_len, sp())
+    assert (o.cpu().double() - ref).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,hd,causal", [(2, 4, 5, 300, 32, 0), (1, 8, 300, 300, 64, 0), (2, 8, 130, 77, 64, 0),
+                                                (2, 8, 64, 64, 64, 1), (1, 2, 33, 100, 128, 0)])
+def test_cross_attention_prefill(B, H, Lq, Lk, hd, causal):
+    rs = np.random.RandomState(Lq * 7 + Lk)
+    E = H * hd
+    q, k, v = rnd(rs, B, Lq, E, scale=0.5), rnd(rs, B, Lk, E), rnd(rs, B, Lk, E)
+    qh, kh, vh = (O.split_heads(t.double(), H) for t in (q, k, v))
+    s = qh @ kh.transpose(-1, -2)
+    if causal:
+        s = s + torch.triu(torch.full((Lq, Lk), float("-inf"), dtype=s.dtype), diagonal=1)
+    ref = O.merge_heads(torch.softmax(s, -1) @ vh)
+    o = torch.empty(B, Lq, E, device="cuda")
+    dq, dk, dv = dev(q), dev(k), dev(v)
+    _lib.call("amt_cross_attn_fwd", _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(o), B, H, Lq, Lk, hd, causal, sp())
+    assert (o.cpu().double() - ref).abs().max() < 2e-5
+
+
+def test_softmax_rescale_branch_forced():
+    """Online-softmax rescale: a late key tile carries a much larger score than every earlier one."""
+    rs = np.random.RandomState(5)
+    B, H, Lq, Lk, hd = 1, 1, 32, 128, 64
+    q, k, v = rnd(rs, B, Lq, hd, scale=0.3), rnd(rs, B, Lk, hd, scale=0.3), rnd(rs, B, Lk, hd)
+    k[0, 100] = q[0, 7] * 40.0          # spike in the 4th tile for one query row
+    k[0, 3] = q[0, 20] * 25.0           # and in the first tile for another
+    s = q.double() @ k.double().transpose(-1, -2)
+    ref = torch.softmax(s, -1) @ v.double()
+    o = torch.empty(B, Lq, hd, device="cuda")
+    dq, dk, dv = dev(q), dev(k), dev(v)
+    _lib.call("amt_cross_attn_fwd", _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(o), B, H, Lq, Lk, hd, 0, sp())
+    assert (o.cpu().double() - ref).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("B,H,hd,cap,pos,rpr", [(1, 4, 32, 300, 0, True), (3, 4, 32, 300, 17, True), (32, 8, 64, 1024, 1023, True),
+                                               (5, 8, 64, 1024, 500, True), (32, 8, 64, 300, 299, False), (2, 2, 128, 64, 63, False),
+                                               (2, 8, 16, 64, 40, False)])
+def test_attention_decode(B, H, hd, cap, pos, rpr):
+    rs = np.random.RandomState(pos + B)
+    q = rnd(rs, B, H * hd, scale=0.5)
+    kc, vc = rnd(rs, B, H, cap, hd), rnd(rs, B, H, cap, hd)
+    er_len = cap + 5
+    Er = torch.from_numpy(rs.uniform(size=(er_len, hd)).astype(np.float32)) if rpr else None
+    qh = q.view(B, H, 1, hd).double()
+    K, Vv = kc[:, :, :pos + 1].double(), vc[:, :, :pos + 1].double()
+    s = qh @ K.transpose(-1, -2)
+    if rpr:       # closed form A1: bias[j] = q . Er[er_len-1-(pos-j)]
+        idx = er_len - 1 - (pos - torch.arange(pos + 1))
+        s = s + torch.einsum("bhqd,jd->bhqj", qh, Er[idx].double())
+    ref = (torch.softmax(s, -1) @ Vv).reshape(B, H * hd)
+    o = torch.empty(B, H * hd, device="cuda")
+    dq, dk, dv, de = dev(q), dev(kc), dev(vc), dev(Er) if rpr else None
+    _lib.call("amt_attn_decode_fwd", _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(de), _lib.ptr(o), B, H, hd, cap, pos,
+              er_len if rpr else 0, sp())
+    assert (o.cpu().double() - ref).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("B,N,K,ln,relu,resid", [(32, 512, 512, True, 0, True), (1, 1536, 512, False, 0, False), (7, 1024, 512, True, 1, False),
+                                                (32, 512, 1024, False, 0, True), (3, 384, 128, True, 0, False), (5, 128, 256, False, 1, True)])
+def test_decode_linear(B, N, K, ln, relu, resid):
+    rs = np.random.RandomState(N + K + B)
+    x, w, b = rnd(rs, B, K, scale=2.0), rnd(rs, N, K, scale=K ** -0.5), rnd(rs, N)
+    lw, lb = (rnd(rs, K), rnd(rs, K)) if ln else (None, None)
+    r = rnd(rs, B, N) if resid else None
+    xn = O.layer_norm(x.double(), lw.double(), lb.double()) if ln else x.double()
+    ref = O.linear(xn, w.double(), b.double())
+    if resid:
+        ref = ref + r.double()
+    if relu:
+        ref = torch.relu(ref)
+    y = torch.empty(B, N, device="cuda")
+    xn_out = torch.zeros(B, K, device="cuda")
+    scratch = torch.empty(((N + 15) // 16) * 16 * K, device="cuda")
+    dx, dw, db = dev(x), dev(w), dev(b)
+    dlw, dlb = (dev(lw), dev(lb)) if ln else (None, None)
+    dr = dev(r) if resid else None
+    _lib.call("amt_decode_linear_fwd", _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(dlw), _lib.ptr(dlb), _lib.ptr(dr),
+              _lib.ptr(y), _lib.ptr(xn_out), _lib.ptr(scratch), B, N, K, relu, 1e-5, sp())
+    assert (y.cpu().double() - ref).abs().max() < 5e-5
+    if ln:
+        assert (xn_out.cpu().double() - xn).abs().max() < 2e-5
+
+
+def test_bad_arguments_fail_loudly():
+    x = torch.zeros(4, 48, device="cuda")
+    with pytest.raises(_lib.AmtError):       # K not a multiple of the k-step
+        _lib.call("amt_linear_fwd", _lib.ptr(x), _lib.ptr(x), None, None, _lib.ptr(x), 4, 4, 48, 0, sp())
+    with pytest.raises(_lib.AmtError):       # unsupported head dim
+        _lib.call("amt_cross_attn_fwd", _lib.ptr(x), _lib.ptr(x), _lib.ptr(x), _lib.ptr(x), 1, 1, 4, 4, 48, 0, sp())

@@ -7,7 +7,7 @@ import torch
 from oracle import amt_oracle as O
 from video2music_amd import synthetic
 from video2music_amd.utilities import constants as C
-from helpers import CFG1, synthetic_sd, feats_t
+from tests.helpers import CFG1, synthetic_sd, feats_t
 
 TOL = 2e-5   # oracle vs reference logits (same fp32 arithmetic, different op grouping)
 

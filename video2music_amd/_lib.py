@@ -1,0 +1,100 @@
+"""ctypes binding of ``libamt_hip.so`` (C ABI declared in ``include/amt_hip.h``).
+
+There is deliberately no CPU fallback: if the shared library is missing, or a call returns a
+non-zero status, this module raises.  Build the library with ``python -c "import __graft_entry__ as
+g; g.build()"`` or ``video2music_amd/csrc/build.sh``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libamt_hip.so")
+
+
+class AmtError(RuntimeError):
+    pass
+
+
+class AmtConfig(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("num_heads", C.c_int32), ("d_model", C.c_int32),
+                ("dim_feedforward", C.c_int32), ("max_sequence_video", C.c_int32),
+                ("max_sequence_chord", C.c_int32), ("total_vf_dim", C.c_int32), ("max_batch", C.c_int32)]
+
+
+_P = C.c_void_p
+_I = C.c_int32
+_F = C.c_float
+
+# name -> argtypes (restype is int32 unless listed in _RESTYPES); mirrors include/amt_hip.h
+SIGNATURES = {
+    "amt_last_error": [],
+    "amt_abi_version": [],
+    "amt_create": [C.POINTER(AmtConfig), C.POINTER(_P)],
+    "amt_destroy": [_P],
+    "amt_load_weight": [_P, C.c_char_p, _P, _I, C.POINTER(C.c_int64)],
+    "amt_finalize": [_P],
+    "amt_encode": [_P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P],
+    "amt_prefill": [_P, _I, _I, _P, _P, _P, _P, _P, _I, _P],
+    "amt_generate_begin": [_P, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P],
+    "amt_generate_run": [_P, _I, _P, _P],
+    "amt_generate_step_probs": [_P, _P, _P],
+    "amt_generate_commit": [_P, _P, _P],
+    "amt_generate_end": [_P, _P, _P],
+    "amt_generate": [_P, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P],
+    "amt_decode_step_bytes": [_P, _I, _I, _I],
+    "amt_linear_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "amt_layernorm_fwd": [_P, _P, _P, _P, _P, _I, _I, _F, _P],
+    "amt_rmsnorm_fwd": [_P, _P, _P, _I, _I, _F, _P],
+    "amt_rope_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "amt_rpr_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "amt_cross_attn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "amt_attn_decode_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "amt_decode_linear_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "amt_gqa_fwd": [_P] * 15 + [_I] * 7 + [_F, _P],
+    "amt_moe_scratch_floats": [_I, _I, _I, _I],
+    "amt_moe_fwd": [_P] * 19 + [_I] * 4 + [_P],
+}
+_RESTYPES = {"amt_last_error": C.c_char_p, "amt_decode_step_bytes": C.c_int64, "amt_moe_scratch_floats": C.c_int64}
+_NO_STATUS = set(_RESTYPES) | {"amt_abi_version"}
+
+_lib = None
+
+
+def load():
+    """Returns the loaded CDLL with typed prototypes; raises AmtError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AmtError(f"{LIB_PATH} is missing: the HIP extension is not built (run __graft_entry__.build()); "
+                       "video2music_amd has no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int32)
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Calls an entry point and raises AmtError with the library's message on a non-zero status."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if name not in _NO_STATUS and rc != 0:
+        msg = lib.amt_last_error()
+        raise AmtError(f"{name} failed (status {rc}): {msg.decode() if msg else '?'}")
+    return rc
+
+
+def ptr(t):
+    """Raw device pointer of a (contiguous) torch tensor, or None."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "libamt_hip takes contiguous tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

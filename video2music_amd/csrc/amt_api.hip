@@ -1,0 +1,722 @@
+// C-ABI layer of libamt_hip: model handle, weight loading/repacking, encoder / prefill / decode
+// orchestration (hipGraph-captured decode step) and the stateless operator entry points.
+// See include/amt_hip.h for the contract and the reference code each entry point replaces.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/amt_hip.h"
+#include "amt_common.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+// error channel
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+void amt_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* amt_last_error(void) { return g_err; }
+extern "C" int32_t amt_abi_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int V = 159;
+constexpr float LN_EPS = 1e-5f;
+constexpr int STEPS_PER_GRAPH = 8;
+
+struct Tensor {
+    float* p = nullptr;
+    std::vector<int64_t> shape;
+    size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; }
+};
+
+struct DecLayer {   // raw + packed weights of one decoder layer
+    const float *sa_w, *sa_b, *Er, *sa_ow, *sa_ob, *ca_w, *ca_b, *ca_ow, *ca_ob, *l1w, *l1b, *l2w, *l2b;
+    const float *n1w, *n1b, *n2w, *n2b, *n3w, *n3b;
+    float *p_sa, *p_sao, *p_caq, *p_cao, *p_l1, *p_l2;   // MFMA-ordered copies for the decode step
+};
+struct EncLayer {
+    const float *sa_w, *sa_b, *sa_ow, *sa_ob, *l1w, *l1b, *l2w, *l2b, *n1w, *n1b, *n2w, *n2b;
+};
+
+}  // namespace
+
+struct amt_handle {
+    amt_config cfg{};
+    int d = 0, H = 0, hd = 0, dff = 0, nl = 0, Scap = 0, Tcap = 0, F = 0, Fpad = 0, maxB = 0;
+    std::map<std::string, Tensor> w;
+    std::vector<void*> owned;            // every hipMalloc of the handle
+    bool finalized = false;
+    std::vector<DecLayer> dec;
+    std::vector<EncLayer> enc;
+    // derived tensors
+    float *Wvis_pad = nullptr, *Wc_main = nullptr, *wkey = nullptr, *PR = nullptr, *PA = nullptr;
+    const float *pe = nullptr, *pe_v = nullptr;
+    // encoder state of the last amt_encode
+    int encB = 0, encS = 0;
+    float* KVx = nullptr;                // [2][nl][maxB][H][Scap][hd]
+    size_t kvx_layer = 0, kvx_part = 0;
+    float* memory = nullptr;             // [maxB*Scap][d]
+    // shared big workspaces (rows = maxB * max(Scap, Tcap))
+    size_t ws_rows = 0;
+    float *wsX = nullptr, *wsU = nullptr, *wsQKV = nullptr, *wsO = nullptr, *wsH = nullptr, *wsA0 = nullptr, *wsQc = nullptr;
+    // decode state
+    float* KVc = nullptr;                // [2][nl][maxB][H][Tcap][hd]
+    size_t kvc_layer = 0, kvc_part = 0;
+    float *x_in = nullptr, *u1 = nullptr, *u2 = nullptr, *u3 = nullptr, *xa = nullptr, *xb = nullptr, *xc = nullptr;
+    float *qb = nullptr, *ob = nullptr, *hb = nullptr, *keyb = nullptr;
+    int* pos = nullptr;
+    unsigned* ticket = nullptr;
+    int64_t *tokens = nullptr, *roots = nullptr, *attrs = nullptr;   // [maxB][Tcap]
+    // current generation
+    int genB = 0, genT = 0, genP = 0, beam = 0, mcN = 0, mcC = 2, steps_done = 0;
+    bool gen_active = false;
+    // graphs keyed by the parameters baked into the captured kernel arguments
+    struct GraphKey { int B, T, P, beam, mcN, mcC, S, nsteps; float* logits; };
+    struct GraphEntry { GraphKey key; hipGraphExec_t exec; hipGraph_t graph; };
+    std::vector<GraphEntry> graphs;
+};
+
+namespace {
+
+template <typename T>
+int32_t dev_alloc(amt_handle* h, T** out, size_t count) {
+    void* p = nullptr;
+    AMT_HIP(hipMalloc(&p, count * sizeof(T) + 256));
+    h->owned.push_back(p);
+    *out = (T*)p;
+    return 0;
+}
+
+const float* W(amt_handle* h, const std::string& name) {
+    auto it = h->w.find(name);
+    return it == h->w.end() ? nullptr : it->second.p;
+}
+
+int32_t need(amt_handle* h, const std::string& name, std::initializer_list<int64_t> shape, const float** out) {
+    auto it = h->w.find(name);
+    AMT_CHECK_ARG(it != h->w.end(), "weight '%s' was not loaded", name.c_str());
+    std::vector<int64_t> want(shape);
+    if (it->second.shape != want) {
+        std::string got, exp;
+        for (auto s : it->second.shape) got += std::to_string(s) + ",";
+        for (auto s : want) exp += std::to_string(s) + ",";
+        AMT_CHECK_ARG(false, "weight '%s' has shape (%s) but the config needs (%s)", name.c_str(), got.c_str(), exp.c_str());
+    }
+    *out = it->second.p;
+    return 0;
+}
+
+int32_t pack(amt_handle* h, const float* w, int N, int K, float** out, hipStream_t s) {
+    int32_t rc = dev_alloc(h, out, (size_t)cdiv(N, 16) * 16 * K);
+    if (rc) return rc;
+    return amt_launch_pack_weight(w, *out, N, K, s);
+}
+
+int32_t ensure_workspace(amt_handle* h) {
+    if (h->wsX) return 0;
+    const size_t R = h->ws_rows;
+    int32_t rc;
+    if ((rc = dev_alloc(h, &h->wsX, R * h->d))) return rc;
+    if ((rc = dev_alloc(h, &h->wsU, R * h->d))) return rc;
+    if ((rc = dev_alloc(h, &h->wsO, R * h->d))) return rc;
+    if ((rc = dev_alloc(h, &h->wsQc, R * h->d))) return rc;
+    if ((rc = dev_alloc(h, &h->wsQKV, R * 3 * h->d))) return rc;
+    if ((rc = dev_alloc(h, &h->wsH, R * h->dff))) return rc;
+    if ((rc = dev_alloc(h, &h->wsA0, (size_t)h->maxB * h->Scap * h->Fpad))) return rc;
+    return 0;
+}
+
+// one decoder/encoder sub-block on [rows][d] activations: U = Linear(O) + resid ; X = LN(U)
+int32_t proj_resid_ln(amt_handle* h, const float* in, int K, const float* w, const float* b, const float* resid,
+                      const float* nw, const float* nb, const float* n2w, const float* n2b, float* U, float* Xout,
+                      int rows, hipStream_t s) {
+    GemmParams g = gemm_params(in, K, w, K, U, h->d, rows, h->d, K, b);
+    g.resid = resid; g.ldr = h->d;
+    int32_t rc = amt_launch_gemm(g, s);
+    if (rc) return rc;
+    return amt_launch_layernorm(U, nullptr, nw, nb, n2w, n2b, Xout, rows, h->d, LN_EPS, s);
+}
+
+int32_t ffn_block(amt_handle* h, float* X, const float* l1w, const float* l1b, const float* l2w, const float* l2b,
+                  const float* nw, const float* nb, const float* n2w, const float* n2b, float* Xout, int rows, hipStream_t s) {
+    GemmParams g = gemm_params(X, h->d, l1w, h->d, h->wsH, h->dff, rows, h->dff, h->d, l1b);
+    g.relu = 1;
+    int32_t rc = amt_launch_gemm(g, s);
+    if (rc) return rc;
+    return proj_resid_ln(h, h->wsH, h->dff, l2w, l2b, X, nw, nb, n2w, n2b, h->wsU, Xout, rows, s);
+}
+
+SampleParams sample_params(amt_handle* h, float* logits_out, float* probs_out, int external) {
+    SampleParams p{};
+    const DecLayer& L = h->dec.back();
+    p.u = h->u3; p.ldu = h->d;
+    p.ln_w = L.n3w; p.ln_b = L.n3b;
+    p.fn_w = W(h, "transformer.decoder.norm.weight"); p.fn_b = W(h, "transformer.decoder.norm.bias");
+    p.Wout = W(h, "Wout.weight"); p.bout = W(h, "Wout.bias");
+    p.eps = LN_EPS; p.B = h->genB; p.d = h->d;
+    p.tokens = h->tokens; p.roots = h->roots; p.attrs = h->attrs; p.T = h->genT;
+    p.pos = h->pos; p.ticket = h->ticket; p.n_primer = h->genP; p.beam = h->beam;
+    p.max_conseq_N = h->mcN; p.max_conseq_chord = h->mcC;
+    p.logits_out = logits_out; p.probs_out = probs_out;
+    p.key = h->keyb; p.PR = h->PR; p.PA = h->PA; p.wkey = h->wkey; p.cbias = W(h, "Linear_chord.bias"); p.pe = h->pe;
+    p.x_next = h->x_in; p.sample_external = external;
+    return p;
+}
+
+// the kernels of one decode step up to (not including) the sampling head
+int32_t enqueue_decoder_step(amt_handle* h, hipStream_t s) {
+    const int B = h->genB, d = h->d, dff = h->dff, H = h->H, hd = h->hd;
+    const float qscale = 1.0f / sqrtf((float)hd);
+    int32_t rc;
+    for (int l = 0; l < h->nl; ++l) {
+        const DecLayer& L = h->dec[l];
+        float* Kc = h->KVc + (size_t)l * h->kvc_layer;
+        float* Vc = Kc + h->kvc_part;
+        const float* Kx = h->KVx + (size_t)l * h->kvx_layer;
+        const float* Vx = Kx + h->kvx_part;
+        // K1: (LN3 of the previous layer) + packed QKV projection, scatter into q / K cache / V cache
+        DecodeGemmParams g{};
+        g.B = B; g.eps = LN_EPS; g.scale = 1.f;
+        g.x = l == 0 ? h->x_in : h->u3; g.ldx = d; g.Wp = L.p_sa; g.bias = L.sa_b; g.N = 3 * d; g.K = d;
+        if (l > 0) { g.ln_w = h->dec[l - 1].n3w; g.ln_b = h->dec[l - 1].n3b; g.xn = h->xa; }
+        g.mode = 1; g.y = h->qb; g.ldy = d; g.scale = qscale; g.scale_cols = d;
+        g.kcache = Kc; g.vcache = Vc; g.H = H; g.hd = hd; g.cap = h->Tcap; g.pos = h->pos; g.d = d;
+        if ((rc = amt_launch_decode_gemm(g, s))) return rc;
+        const float* r0 = l == 0 ? h->x_in : h->xa;
+        // K2: relative-position self-attention over the cache
+        AttnDecodeParams a{};
+        a.q = h->qb; a.k = Kc; a.v = Vc; a.o = h->ob; a.B = B; a.H = H; a.hd = hd; a.cap = h->Tcap;
+        a.pos = h->pos; a.Er = L.Er; a.er_len = h->Tcap;
+        if ((rc = amt_launch_attn_decode(a, s))) return rc;
+        // K3: out-proj + residual
+        DecodeGemmParams o{};
+        o.B = B; o.eps = LN_EPS; o.scale = 1.f; o.x = h->ob; o.ldx = d; o.Wp = L.p_sao; o.bias = L.sa_ob; o.N = d; o.K = d;
+        o.resid = r0; o.ldr = d; o.y = h->u1; o.ldy = d;
+        if ((rc = amt_launch_decode_gemm(o, s))) return rc;
+        // K4: LN1 + cross-attention query projection
+        DecodeGemmParams c{};
+        c.B = B; c.eps = LN_EPS; c.x = h->u1; c.ldx = d; c.Wp = L.p_caq; c.bias = L.ca_b; c.N = d; c.K = d;
+        c.ln_w = L.n1w; c.ln_b = L.n1b; c.xn = h->xb; c.scale = qscale; c.scale_cols = d; c.y = h->qb; c.ldy = d;
+        if ((rc = amt_launch_decode_gemm(c, s))) return rc;
+        // K5: cross-attention over the clip's video keys
+        AttnDecodeParams x{};
+        x.q = h->qb; x.k = Kx; x.v = Vx; x.o = h->ob; x.B = B; x.H = H; x.hd = hd; x.cap = h->Scap; x.n_keys = h->encS;
+        if ((rc = amt_launch_attn_decode(x, s))) return rc;
+        // K6: out-proj + residual
+        DecodeGemmParams o2{};
+        o2.B = B; o2.eps = LN_EPS; o2.scale = 1.f; o2.x = h->ob; o2.ldx = d; o2.Wp = L.p_cao; o2.bias = L.ca_ob; o2.N = d; o2.K = d;
+        o2.resid = h->xb; o2.ldr = d; o2.y = h->u2; o2.ldy = d;
+        if ((rc = amt_launch_decode_gemm(o2, s))) return rc;
+        // K7: LN2 + FFN up + ReLU
+        DecodeGemmParams f1{};
+        f1.B = B; f1.eps = LN_EPS; f1.scale = 1.f; f1.x = h->u2; f1.ldx = d; f1.Wp = L.p_l1; f1.bias = L.l1b; f1.N = dff; f1.K = d;
+        f1.ln_w = L.n2w; f1.ln_b = L.n2b; f1.xn = h->xc; f1.relu = 1; f1.y = h->hb; f1.ldy = dff;
+        if ((rc = amt_launch_decode_gemm(f1, s))) return rc;
+        // K8: FFN down + residual
+        DecodeGemmParams f2{};
+        f2.B = B; f2.eps = LN_EPS; f2.scale = 1.f; f2.x = h->hb; f2.ldx = dff; f2.Wp = L.p_l2; f2.bias = L.l2b; f2.N = d; f2.K = dff;
+        f2.resid = h->xc; f2.ldr = d; f2.y = h->u3; f2.ldy = d;
+        if ((rc = amt_launch_decode_gemm(f2, s))) return rc;
+    }
+    return 0;
+}
+
+int32_t get_graph(amt_handle* h, int nsteps, float* logits_out, hipStream_t s, hipGraphExec_t* out) {
+    amt_handle::GraphKey key{h->genB, h->genT, h->genP, h->beam, h->mcN, h->mcC, h->encS, nsteps, logits_out};
+    for (auto& g : h->graphs)
+        if (memcmp(&g.key, &key, sizeof(key)) == 0) { *out = g.exec; return 0; }
+    hipGraph_t graph;
+    AMT_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    int32_t rc = 0;
+    for (int i = 0; i < nsteps && !rc; ++i) {
+        rc = enqueue_decoder_step(h, s);
+        if (!rc) rc = amt_launch_sample(sample_params(h, logits_out, nullptr, 0), s);
+    }
+    hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc) { if (e == hipSuccess) (void)hipGraphDestroy(graph); return rc; }
+    AMT_HIP(e);
+    hipGraphExec_t exec;
+    AMT_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    h->graphs.push_back({key, exec, graph});
+    *out = exec;
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// lifetime
+// ------------------------------------------------------------------------------------------------
+extern "C" int32_t amt_create(const amt_config* c, amt_handle** out) {
+    AMT_CHECK_ARG(c && out, "amt_create: null argument");
+    AMT_CHECK_ARG(c->n_layers > 0 && c->num_heads > 0 && c->d_model > 0 && c->dim_feedforward > 0, "amt_create: bad model dims");
+    AMT_CHECK_ARG(c->d_model % c->num_heads == 0, "amt_create: d_model %% num_heads != 0");
+    const int hd = c->d_model / c->num_heads;
+    AMT_CHECK_ARG(hd == 32 || hd == 64 || hd == 128, "amt_create: head_dim %d not in {32,64,128}", hd);
+    AMT_CHECK_ARG(c->d_model % 64 == 0 && c->d_model <= 1024, "amt_create: d_model must be a multiple of 64 and <= 1024");
+    AMT_CHECK_ARG(c->dim_feedforward % 64 == 0 && c->dim_feedforward <= 1024, "amt_create: dim_feedforward must be a multiple of 64 and <= 1024");
+    AMT_CHECK_ARG(c->max_batch > 0 && c->max_batch <= 32, "amt_create: max_batch must be in 1..32 (shard larger batches)");
+    AMT_CHECK_ARG(c->max_sequence_video > 0 && c->max_sequence_chord > 0 && c->total_vf_dim > 0, "amt_create: bad sequence dims");
+    amt_handle* h = new amt_handle();
+    h->cfg = *c;
+    h->d = c->d_model; h->H = c->num_heads; h->hd = hd; h->dff = c->dim_feedforward; h->nl = c->n_layers;
+    h->Scap = c->max_sequence_video; h->Tcap = c->max_sequence_chord; h->F = c->total_vf_dim;
+    h->Fpad = cdiv(h->F, 32) * 32; h->maxB = c->max_batch;
+    h->ws_rows = (size_t)h->maxB * (size_t)(h->Scap > h->Tcap ? h->Scap : h->Tcap);
+    *out = h;
+    return 0;
+}
+
+extern "C" int32_t amt_destroy(amt_handle* h) {
+    if (!h) return 0;
+    (void)hipDeviceSynchronize();
+    for (auto& g : h->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+    for (void* p : h->owned) (void)hipFree(p);
+    delete h;
+    return 0;
+}
+
+extern "C" int32_t amt_load_weight(amt_handle* h, const char* name, const float* data, int32_t ndim, const int64_t* shape) {
+    AMT_CHECK_ARG(h && name && data && ndim > 0 && ndim <= 4 && shape, "amt_load_weight: bad argument");
+    Tensor t;
+    t.shape.assign(shape, shape + ndim);
+    const size_t n = t.numel();
+    AMT_CHECK_ARG(n > 0, "amt_load_weight: empty tensor '%s'", name);
+    auto it = h->w.find(name);
+    if (it != h->w.end() && it->second.numel() == n) {
+        t.p = it->second.p;                          // reload in place
+    } else {
+        int32_t rc = dev_alloc(h, &t.p, n);
+        if (rc) return rc;
+    }
+    AMT_HIP(hipMemcpy(t.p, data, n * sizeof(float), hipMemcpyDefault));
+    h->w[name] = t;
+    h->finalized = false;
+    return 0;
+}
+
+extern "C" int32_t amt_finalize(amt_handle* h) {
+    AMT_CHECK_ARG(h, "amt_finalize: null handle");
+    const int64_t d = h->d, dff = h->dff, F = h->F, hd = h->hd;
+    hipStream_t s = nullptr;
+    int32_t rc;
+    const float *Wvis, *bvis, *Wc, *bc, *Eroot, *Eattr, *Wout, *bout, *enw, *enb, *dnw, *dnb;
+    if ((rc = need(h, "Linear_vis.weight", {d, F}, &Wvis))) return rc;
+    if ((rc = need(h, "Linear_vis.bias", {d}, &bvis))) return rc;
+    if ((rc = need(h, "Linear_chord.weight", {d, d + 1}, &Wc))) return rc;
+    if ((rc = need(h, "Linear_chord.bias", {d}, &bc))) return rc;
+    if ((rc = need(h, "embedding_root.weight", {15, d}, &Eroot))) return rc;
+    if ((rc = need(h, "embedding_attr.weight", {16, d}, &Eattr))) return rc;
+    if ((rc = need(h, "Wout.weight", {V, d}, &Wout))) return rc;
+    if ((rc = need(h, "Wout.bias", {V}, &bout))) return rc;
+    if ((rc = need(h, "transformer.encoder.norm.weight", {d}, &enw))) return rc;
+    if ((rc = need(h, "transformer.encoder.norm.bias", {d}, &enb))) return rc;
+    if ((rc = need(h, "transformer.decoder.norm.weight", {d}, &dnw))) return rc;
+    if ((rc = need(h, "transformer.decoder.norm.bias", {d}, &dnb))) return rc;
+    if ((rc = need(h, "positional_encoding.pe", {h->Tcap, 1, d}, &h->pe))) return rc;
+    if ((rc = need(h, "positional_encoding_video.pe", {h->Scap, 1, d}, &h->pe_v))) return rc;
+
+    h->enc.assign(h->nl, EncLayer{});
+    h->dec.assign(h->nl, DecLayer{});
+    for (int l = 0; l < h->nl; ++l) {
+        const std::string e = "transformer.encoder.layers." + std::to_string(l) + ".";
+        EncLayer& E = h->enc[l];
+        if ((rc = need(h, e + "self_attn.in_proj_weight", {3 * d, d}, &E.sa_w))) return rc;
+        if ((rc = need(h, e + "self_attn.in_proj_bias", {3 * d}, &E.sa_b))) return rc;
+        if ((rc = need(h, e + "self_attn.out_proj.weight", {d, d}, &E.sa_ow))) return rc;
+        if ((rc = need(h, e + "self_attn.out_proj.bias", {d}, &E.sa_ob))) return rc;
+        if ((rc = need(h, e + "linear1.weight", {dff, d}, &E.l1w))) return rc;
+        if ((rc = need(h, e + "linear1.bias", {dff}, &E.l1b))) return rc;
+        if ((rc = need(h, e + "linear2.weight", {d, dff}, &E.l2w))) return rc;
+        if ((rc = need(h, e + "linear2.bias", {d}, &E.l2b))) return rc;
+        if ((rc = need(h, e + "norm1.weight", {d}, &E.n1w))) return rc;
+        if ((rc = need(h, e + "norm1.bias", {d}, &E.n1b))) return rc;
+        if ((rc = need(h, e + "norm2.weight", {d}, &E.n2w))) return rc;
+        if ((rc = need(h, e + "norm2.bias", {d}, &E.n2b))) return rc;
+        const std::string p = "transformer.decoder.layers." + std::to_string(l) + ".";
+        DecLayer& D = h->dec[l];
+        if ((rc = need(h, p + "self_attn.in_proj_weight", {3 * d, d}, &D.sa_w))) return rc;
+        if ((rc = need(h, p + "self_attn.in_proj_bias", {3 * d}, &D.sa_b))) return rc;
+        if ((rc = need(h, p + "self_attn.Er", {h->Tcap, hd}, &D.Er))) return rc;
+        if ((rc = need(h, p + "self_attn.out_proj.weight", {d, d}, &D.sa_ow))) return rc;
+        if ((rc = need(h, p + "self_attn.out_proj.bias", {d}, &D.sa_ob))) return rc;
+        if ((rc = need(h, p + "multihead_attn.in_proj_weight", {3 * d, d}, &D.ca_w))) return rc;
+        if ((rc = need(h, p + "multihead_attn.in_proj_bias", {3 * d}, &D.ca_b))) return rc;
+        if ((rc = need(h, p + "multihead_attn.out_proj.weight", {d, d}, &D.ca_ow))) return rc;
+        if ((rc = need(h, p + "multihead_attn.out_proj.bias", {d}, &D.ca_ob))) return rc;
+        if ((rc = need(h, p + "linear1.weight", {dff, d}, &D.l1w))) return rc;
+        if ((rc = need(h, p + "linear1.bias", {dff}, &D.l1b))) return rc;
+        if ((rc = need(h, p + "linear2.weight", {d, dff}, &D.l2w))) return rc;
+        if ((rc = need(h, p + "linear2.bias", {d}, &D.l2b))) return rc;
+        if ((rc = need(h, p + "norm1.weight", {d}, &D.n1w))) return rc;
+        if ((rc = need(h, p + "norm1.bias", {d}, &D.n1b))) return rc;
+        if ((rc = need(h, p + "norm2.weight", {d}, &D.n2w))) return rc;
+        if ((rc = need(h, p + "norm2.bias", {d}, &D.n2b))) return rc;
+        if ((rc = need(h, p + "norm3.weight", {d}, &D.n3w))) return rc;
+        if ((rc = need(h, p + "norm3.bias", {d}, &D.n3b))) return rc;
+    }
+
+    if (!h->KVx) {   // first finalize: allocate the persistent state
+        h->kvx_part = (size_t)h->nl * h->maxB * h->H * h->Scap * h->hd;
+        h->kvx_layer = (size_t)h->maxB * h->H * h->Scap * h->hd;
+        h->kvc_part = (size_t)h->nl * h->maxB * h->H * h->Tcap * h->hd;
+        h->kvc_layer = (size_t)h->maxB * h->H * h->Tcap * h->hd;
+        if ((rc = dev_alloc(h, &h->KVx, 2 * h->kvx_part))) return rc;
+        if ((rc = dev_alloc(h, &h->KVc, 2 * h->kvc_part))) return rc;
+        if ((rc = dev_alloc(h, &h->memory, (size_t)h->maxB * h->Scap * d))) return rc;
+        if ((rc = dev_alloc(h, &h->Wvis_pad, (size_t)d * h->Fpad))) return rc;
+        if ((rc = dev_alloc(h, &h->Wc_main, (size_t)d * d))) return rc;
+        if ((rc = dev_alloc(h, &h->wkey, (size_t)d))) return rc;
+        if ((rc = dev_alloc(h, &h->PR, (size_t)15 * d))) return rc;
+        if ((rc = dev_alloc(h, &h->PA, (size_t)16 * d))) return rc;
+        const size_t bd = (size_t)32 * d;
+        if ((rc = dev_alloc(h, &h->x_in, bd))) return rc;
+        if ((rc = dev_alloc(h, &h->u1, bd))) return rc;
+        if ((rc = dev_alloc(h, &h->u2, bd))) return rc;
+        if ((rc = dev_alloc(h, &h->u3, bd))) return rc;
+        if ((rc = dev_alloc(h, &h->xa, bd))) return rc;
+        if ((rc = dev_alloc(h, &h->xb, bd))) return rc;
+        if ((rc = dev_alloc(h, &h->xc, bd))) return rc;
+        if ((rc = dev_alloc(h, &h->qb, bd))) return rc;
+        if ((rc = dev_alloc(h, &h->ob, bd))) return rc;
+        if ((rc = dev_alloc(h, &h->hb, (size_t)32 * dff))) return rc;
+        if ((rc = dev_alloc(h, &h->keyb, (size_t)32))) return rc;
+        if ((rc = dev_alloc(h, &h->pos, (size_t)4))) return rc;
+        if ((rc = dev_alloc(h, &h->ticket, (size_t)4))) return rc;
+        if ((rc = dev_alloc(h, &h->tokens, (size_t)h->maxB * h->Tcap))) return rc;
+        if ((rc = dev_alloc(h, &h->roots, (size_t)h->maxB * h->Tcap))) return rc;
+        if ((rc = dev_alloc(h, &h->attrs, (size_t)h->maxB * h->Tcap))) return rc;
+        AMT_HIP(hipMemset(h->pos, 0, 16));
+        AMT_HIP(hipMemset(h->ticket, 0, 16));
+    }
+    // Linear_vis zero-padded to a multiple of the GEMM K-step; Linear_chord split into its d x d
+    // block and the key column (video_music_transformer.py:999-1001: cat([x, key]) -> Linear(d+1, d))
+    AMT_HIP(hipMemset(h->Wvis_pad, 0, (size_t)d * h->Fpad * sizeof(float)));
+    AMT_HIP(hipMemcpy2D(h->Wvis_pad, h->Fpad * sizeof(float), Wvis, F * sizeof(float), F * sizeof(float), d, hipMemcpyDeviceToDevice));
+    AMT_HIP(hipMemcpy2D(h->Wc_main, d * sizeof(float), Wc, (d + 1) * sizeof(float), d * sizeof(float), d, hipMemcpyDeviceToDevice));
+    AMT_HIP(hipMemcpy2D(h->wkey, sizeof(float), Wc + d, (d + 1) * sizeof(float), sizeof(float), d, hipMemcpyDeviceToDevice));
+    // PR = E_root . Wc_main^T, PA = E_attr . Wc_main^T
+    if ((rc = amt_launch_gemm(gemm_params(Eroot, (int)d, h->Wc_main, (int)d, h->PR, (int)d, 15, (int)d, (int)d, nullptr), s))) return rc;
+    if ((rc = amt_launch_gemm(gemm_params(Eattr, (int)d, h->Wc_main, (int)d, h->PA, (int)d, 16, (int)d, (int)d, nullptr), s))) return rc;
+    for (int l = 0; l < h->nl; ++l) {
+        DecLayer& D = h->dec[l];
+        if (!D.p_sa) {
+            if ((rc = pack(h, D.sa_w, 3 * (int)d, (int)d, &D.p_sa, s))) return rc;
+            if ((rc = pack(h, D.sa_ow, (int)d, (int)d, &D.p_sao, s))) return rc;
+            if ((rc = pack(h, D.ca_w, (int)d, (int)d, &D.p_caq, s))) return rc;      // q rows 0:d of the packed in-proj
+            if ((rc = pack(h, D.ca_ow, (int)d, (int)d, &D.p_cao, s))) return rc;
+            if ((rc = pack(h, D.l1w, (int)dff, (int)d, &D.p_l1, s))) return rc;
+            if ((rc = pack(h, D.l2w, (int)d, (int)dff, &D.p_l2, s))) return rc;
+        }
+    }
+    AMT_HIP(hipDeviceSynchronize());
+    // captured graphs hold pointers that stay valid (weights reload in place), nothing to invalidate
+    h->finalized = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// encoder
+// ------------------------------------------------------------------------------------------------
+extern "C" int32_t amt_encode(amt_handle* h, int32_t B, int32_t S, const float* sem, int32_t sem_dim, const float* scene,
+                              const float* motion, int32_t motion_dim, const float* emotion, int32_t emo_dim,
+                              float* memory_out, void* stream) {
+    AMT_CHECK_ARG(h && h->finalized, "amt_encode: handle not finalized");
+    AMT_CHECK_ARG(B > 0 && B <= h->maxB, "amt_encode: B=%d outside 1..%d", B, h->maxB);
+    AMT_CHECK_ARG(S > 0 && S <= h->Scap, "amt_encode: S=%d outside 1..%d", S, h->Scap);
+    AMT_CHECK_ARG(sem_dim + 1 + motion_dim + emo_dim == h->F, "amt_encode: feature widths %d+1+%d+%d != total_vf_dim %d",
+                  sem_dim, motion_dim, emo_dim, h->F);
+    AMT_CHECK_ARG(sem && scene && motion && emotion, "amt_encode: null feature pointer");
+    hipStream_t s = (hipStream_t)stream;
+    int32_t rc = ensure_workspace(h);
+    if (rc) return rc;
+    const int d = h->d, R = B * S;
+    const float qscale = 1.0f / sqrtf((float)h->hd);
+    if ((rc = amt_launch_concat_features(sem, sem_dim, scene, motion, motion_dim, emotion, emo_dim, h->wsA0, R, h->Fpad, s))) return rc;
+    {   // Linear_vis + positional encoding of the frame index
+        GemmParams g = gemm_params(h->wsA0, h->Fpad, h->Wvis_pad, h->Fpad, h->wsX, d, R, d, h->Fpad, W(h, "Linear_vis.bias"));
+        g.rowadd = h->pe_v; g.rowadd_period = S;
+        if ((rc = amt_launch_gemm(g, s))) return rc;
+    }
+    for (int l = 0; l < h->nl; ++l) {
+        const EncLayer& E = h->enc[l];
+        GemmParams g = gemm_params(h->wsX, d, E.sa_w, d, h->wsQKV, 3 * d, R, 3 * d, d, E.sa_b);
+        g.scale = qscale; g.scale_cols = d;
+        if ((rc = amt_launch_gemm(g, s))) return rc;
+        AttnParams a{};
+        a.q = h->wsQKV; a.k = h->wsQKV + d; a.v = h->wsQKV + 2 * d; a.o = h->wsO;
+        a.q_bs = a.k_bs = a.v_bs = (size_t)S * 3 * d; a.q_hs = a.k_hs = a.v_hs = h->hd; a.q_ls = a.k_ls = a.v_ls = 3 * d;
+        a.o_bs = (size_t)S * d; a.o_hs = h->hd; a.o_ls = d;
+        a.B = B; a.H = h->H; a.Lq = S; a.Lk = S; a.hd = h->hd; a.kv_group = 1;
+        if ((rc = amt_launch_attn_prefill(a, s))) return rc;
+        if ((rc = proj_resid_ln(h, h->wsO, d, E.sa_ow, E.sa_ob, h->wsX, E.n1w, E.n1b, nullptr, nullptr, h->wsU, h->wsX, R, s))) return rc;
+        const bool last = l == h->nl - 1;
+        if ((rc = ffn_block(h, h->wsX, E.l1w, E.l1b, E.l2w, E.l2b, E.n2w, E.n2b,
+                            last ? W(h, "transformer.encoder.norm.weight") : nullptr,
+                            last ? W(h, "transformer.encoder.norm.bias") : nullptr,
+                            last ? h->memory : h->wsX, R, s))) return rc;
+    }
+    if (memory_out) AMT_HIP(hipMemcpyAsync(memory_out, h->memory, (size_t)R * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // per decoder layer: K,V = memory . W[d:3d]^T + b[d:3d], stored head-major for the streaming decode kernel
+    for (int l = 0; l < h->nl; ++l) {
+        const DecLayer& D = h->dec[l];
+        GemmParams g = gemm_params(h->memory, d, D.ca_w + (size_t)d * d, d, h->KVx + (size_t)l * h->kvx_layer, 0, R, 2 * d, d, D.ca_b + d);
+        g.head_split = 1; g.hs_seq = S; g.hs_seq_cap = h->Scap; g.hs_d = d; g.hs_hd = h->hd; g.hs_heads = h->H;
+        g.hs_part_stride = h->kvx_part;
+        if ((rc = amt_launch_gemm(g, s))) return rc;
+    }
+    h->encB = B; h->encS = S;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// teacher-forced decoder pass
+// ------------------------------------------------------------------------------------------------
+extern "C" int32_t amt_prefill(amt_handle* h, int32_t B, int32_t L, const int64_t* root_ids, const int64_t* attr_ids,
+                               const float* key, float* logits_out, float* layer_out, int32_t layer_index, void* stream) {
+    AMT_CHECK_ARG(h && h->finalized, "amt_prefill: handle not finalized");
+    AMT_CHECK_ARG(B > 0 && B == h->encB, "amt_prefill: B=%d does not match the last amt_encode (B=%d)", B, h->encB);
+    AMT_CHECK_ARG(L > 0 && L <= h->Tcap, "amt_prefill: L=%d outside 1..%d (max_sequence_chord)", L, h->Tcap);
+    AMT_CHECK_ARG(root_ids && attr_ids && key && logits_out, "amt_prefill: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    int32_t rc = ensure_workspace(h);
+    if (rc) return rc;
+    const int d = h->d, R = B * L, S = h->encS;
+    const float qscale = 1.0f / sqrtf((float)h->hd);
+    if ((rc = amt_launch_chord_embed(root_ids, attr_ids, key, h->PR, h->PA, h->wkey, W(h, "Linear_chord.bias"), h->pe, h->wsX, B, L, d, s))) return rc;
+    for (int l = 0; l < h->nl; ++l) {
+        const DecLayer& D = h->dec[l];
+        GemmParams g = gemm_params(h->wsX, d, D.sa_w, d, h->wsQKV, 3 * d, R, 3 * d, d, D.sa_b);
+        g.scale = qscale; g.scale_cols = d;
+        if ((rc = amt_launch_gemm(g, s))) return rc;
+        AttnParams a{};
+        a.q = h->wsQKV; a.k = h->wsQKV + d; a.v = h->wsQKV + 2 * d; a.o = h->wsO;
+        a.q_bs = a.k_bs = a.v_bs = (size_t)L * 3 * d; a.q_hs = a.k_hs = a.v_hs = h->hd; a.q_ls = a.k_ls = a.v_ls = 3 * d;
+        a.o_bs = (size_t)L * d; a.o_hs = h->hd; a.o_ls = d;
+        a.B = B; a.H = h->H; a.Lq = L; a.Lk = L; a.hd = h->hd; a.causal = 1; a.Er = D.Er; a.er_len = h->Tcap; a.kv_group = 1;
+        if ((rc = amt_launch_attn_prefill(a, s))) return rc;
+        if ((rc = proj_resid_ln(h, h->wsO, d, D.sa_ow, D.sa_ob, h->wsX, D.n1w, D.n1b, nullptr, nullptr, h->wsU, h->wsX, R, s))) return rc;
+        // cross-attention: q from the chord stream, K/V precomputed per clip by amt_encode
+        GemmParams q = gemm_params(h->wsX, d, D.ca_w, d, h->wsQc, d, R, d, d, D.ca_b);
+        q.scale = qscale; q.scale_cols = d;
+        if ((rc = amt_launch_gemm(q, s))) return rc;
+        AttnParams c{};
+        c.q = h->wsQc; c.k = h->KVx + (size_t)l * h->kvx_layer; c.v = c.k + h->kvx_part; c.o = h->wsO;
+        c.q_bs = (size_t)L * d; c.q_hs = h->hd; c.q_ls = d;
+        c.k_bs = c.v_bs = (size_t)h->H * h->Scap * h->hd; c.k_hs = c.v_hs = (size_t)h->Scap * h->hd; c.k_ls = c.v_ls = h->hd;
+        c.o_bs = (size_t)L * d; c.o_hs = h->hd; c.o_ls = d;
+        c.B = B; c.H = h->H; c.Lq = L; c.Lk = S; c.hd = h->hd; c.kv_group = 1;
+        if ((rc = amt_launch_attn_prefill(c, s))) return rc;
+        if ((rc = proj_resid_ln(h, h->wsO, d, D.ca_ow, D.ca_ob, h->wsX, D.n2w, D.n2b, nullptr, nullptr, h->wsU, h->wsX, R, s))) return rc;
+        if ((rc = ffn_block(h, h->wsX, D.l1w, D.l1b, D.l2w, D.l2b, D.n3w, D.n3b, nullptr, nullptr, h->wsX, R, s))) return rc;
+        if (layer_out && l == layer_index)
+            AMT_HIP(hipMemcpyAsync(layer_out, h->wsX, (size_t)R * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    if ((rc = amt_launch_layernorm(h->wsX, nullptr, W(h, "transformer.decoder.norm.weight"), W(h, "transformer.decoder.norm.bias"),
+                                   nullptr, nullptr, h->wsU, R, d, LN_EPS, s))) return rc;
+    GemmParams g = gemm_params(h->wsU, d, W(h, "Wout.weight"), d, logits_out, V, R, V, d, W(h, "Wout.bias"));
+    return amt_launch_gemm(g, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// generate
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ void init_sequences_kernel(int64_t* tokens, int64_t* roots, int64_t* attrs, const int64_t* primer,
+                                      const int64_t* primer_root, const int64_t* primer_attr, int P, int per_clip, int T) {
+    const int b = blockIdx.x;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        int64_t tk = 158, r = 14, a = 15;            // CHORD_PAD, CHORD_ROOT_PAD, CHORD_ATTR_PAD
+        if (t < P) {
+            const size_t i = per_clip ? (size_t)b * P + t : (size_t)t;
+            tk = primer[i]; r = primer_root[i]; a = primer_attr[i];
+        }
+        tokens[(size_t)b * T + t] = tk; roots[(size_t)b * T + t] = r; attrs[(size_t)b * T + t] = a;
+    }
+}
+}  // namespace
+
+extern "C" int32_t amt_generate_begin(amt_handle* h, int32_t B, const int64_t* primer, const int64_t* primer_root,
+                                      const int64_t* primer_attr, int32_t P, int32_t primer_per_clip, const float* key,
+                                      int32_t T, int32_t beam, int32_t max_conseq_N, int32_t max_conseq_chord, void* stream) {
+    AMT_CHECK_ARG(h && h->finalized, "amt_generate: handle not finalized");
+    AMT_CHECK_ARG(B > 0 && B == h->encB, "amt_generate: B=%d does not match the last amt_encode (B=%d)", B, h->encB);
+    AMT_CHECK_ARG(T > 0 && T <= h->Tcap, "amt_generate: target_seq_length=%d outside 1..%d (max_sequence_chord)", T, h->Tcap);
+    AMT_CHECK_ARG(P > 0 && P <= T, "amt_generate: primer length %d outside 1..%d", P, T);
+    AMT_CHECK_ARG(beam == 0 || beam == 1, "amt_generate: beam=%d is not supported (0 = sampling branch, 1 = top-1 branch)", beam);
+    AMT_CHECK_ARG(max_conseq_chord >= 1, "amt_generate: max_conseq_chord must be >= 1");
+    AMT_CHECK_ARG(primer && primer_root && primer_attr && key, "amt_generate: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    h->genB = B; h->genT = T; h->genP = P; h->beam = beam; h->mcN = max_conseq_N; h->mcC = max_conseq_chord;
+    h->steps_done = 0; h->gen_active = true;
+    hipLaunchKernelGGL(init_sequences_kernel, dim3(B), dim3(256), 0, s, h->tokens, h->roots, h->attrs, primer, primer_root,
+                       primer_attr, P, primer_per_clip, T);
+    AMT_LAUNCH_CHECK();
+    AMT_HIP(hipMemcpyAsync(h->keyb, key, B * sizeof(float), hipMemcpyDeviceToDevice, s));
+    AMT_HIP(hipMemsetAsync(h->pos, 0, 16, s));
+    AMT_HIP(hipMemsetAsync(h->ticket, 0, 16, s));
+    return amt_launch_embed_step(sample_params(h, nullptr, nullptr, 0), 0, s);     // x_in for position 0
+}
+
+extern "C" int32_t amt_generate_run(amt_handle* h, int32_t n_steps, float* logits_out, void* stream) {
+    AMT_CHECK_ARG(h && h->gen_active, "amt_generate_run: no generation in progress");
+    hipStream_t s = (hipStream_t)stream;
+    const int remaining = h->genT - 1 - h->steps_done;
+    if (n_steps < 0 || n_steps > remaining) n_steps = remaining;
+    int32_t rc;
+    int left = n_steps;
+    while (left > 0) {
+        const int ns = left >= STEPS_PER_GRAPH ? STEPS_PER_GRAPH : 1;
+        hipGraphExec_t exec;
+        if ((rc = get_graph(h, ns, logits_out, s, &exec))) return rc;
+        AMT_HIP(hipGraphLaunch(exec, s));
+        left -= ns;
+    }
+    h->steps_done += n_steps;
+    return 0;
+}
+
+extern "C" int32_t amt_generate_step_probs(amt_handle* h, float* probs_out, void* stream) {
+    AMT_CHECK_ARG(h && h->gen_active && probs_out, "amt_generate_step_probs: no generation in progress");
+    AMT_CHECK_ARG(h->steps_done < h->genT - 1, "amt_generate_step_probs: sequence is complete");
+    hipStream_t s = (hipStream_t)stream;
+    int32_t rc = enqueue_decoder_step(h, s);
+    if (rc) return rc;
+    return amt_launch_sample(sample_params(h, nullptr, probs_out, 1), s);
+}
+
+namespace {
+__global__ void commit_tokens_kernel(int64_t* tokens, const int64_t* chosen, const int* pos, int T, int n_primer) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cur = *pos + 1;
+    if (b < gridDim.x * blockDim.x && cur < T && cur >= n_primer) tokens[(size_t)b * T + cur] = chosen[b];
+}
+}  // namespace
+
+extern "C" int32_t amt_generate_commit(amt_handle* h, const int64_t* chosen, void* stream) {
+    AMT_CHECK_ARG(h && h->gen_active && chosen, "amt_generate_commit: no generation in progress");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(commit_tokens_kernel, dim3(1), dim3(h->genB), 0, s, h->tokens, chosen, h->pos, h->genT, h->genP);
+    AMT_LAUNCH_CHECK();
+    int32_t rc = amt_launch_embed_step(sample_params(h, nullptr, nullptr, 1), 1, s);
+    if (rc) return rc;
+    h->steps_done += 1;
+    return 0;
+}
+
+extern "C" int32_t amt_generate_end(amt_handle* h, int64_t* tokens_out, void* stream) {
+    AMT_CHECK_ARG(h && h->gen_active && tokens_out, "amt_generate_end: no generation in progress");
+    AMT_HIP(hipMemcpyAsync(tokens_out, h->tokens, (size_t)h->genB * h->genT * sizeof(int64_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int32_t amt_generate(amt_handle* h, int32_t B, const int64_t* primer, const int64_t* primer_root,
+                                const int64_t* primer_attr, int32_t P, int32_t primer_per_clip, const float* key,
+                                int32_t T, int32_t beam, int32_t max_conseq_N, int32_t max_conseq_chord,
+                                int64_t* tokens_out, float* logits_out, void* stream) {
+    int32_t rc = amt_generate_begin(h, B, primer, primer_root, primer_attr, P, primer_per_clip, key, T, beam,
+                                    max_conseq_N, max_conseq_chord, stream);
+    if (rc) return rc;
+    if ((rc = amt_generate_run(h, -1, logits_out, stream))) return rc;
+    return amt_generate_end(h, tokens_out, stream);
+}
+
+extern "C" int64_t amt_decode_step_bytes(const amt_handle* h, int32_t B, int32_t n_self_keys, int32_t S) {
+    if (!h) return 0;
+    // K and V rows streamed by the two attention kernels of every layer (fp32)
+    const int64_t row = (int64_t)h->d * 4 * 2;
+    return (int64_t)h->nl * B * ((int64_t)n_self_keys + S) * row;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stateless operator entry points
+// ------------------------------------------------------------------------------------------------
+extern "C" int32_t amt_linear_fwd(const float* x, const float* w, const float* bias, const float* resid, float* y,
+                                  int32_t M, int32_t N, int32_t K, int32_t relu, void* stream) {
+    AMT_CHECK_ARG(x && w && y, "amt_linear_fwd: null pointer");
+    GemmParams g = gemm_params(x, K, w, K, y, N, M, N, K, bias);
+    g.resid = resid; g.ldr = N; g.relu = relu;
+    return amt_launch_gemm(g, (hipStream_t)stream);
+}
+
+extern "C" int32_t amt_layernorm_fwd(const float* x, const float* resid, const float* w, const float* b, float* y,
+                                     int32_t rows, int32_t dim, float eps, void* stream) {
+    AMT_CHECK_ARG(x && y, "amt_layernorm_fwd: null pointer");
+    return amt_launch_layernorm(x, resid, w, b, nullptr, nullptr, y, rows, dim, eps, (hipStream_t)stream);
+}
+
+extern "C" int32_t amt_rmsnorm_fwd(const float* x, const float* w, float* y, int32_t rows, int32_t dim, float eps, void* stream) {
+    AMT_CHECK_ARG(x && y, "amt_rmsnorm_fwd: null pointer");
+    return amt_launch_rmsnorm(x, w, y, rows, dim, eps, (hipStream_t)stream);
+}
+
+extern "C" int32_t amt_rope_fwd(const float* x, const float* cache, float* y, int32_t n0, int32_t seq, int32_t n2, int32_t hd,
+                                int32_t cache_half, void* stream) {
+    AMT_CHECK_ARG(x && cache && y, "amt_rope_fwd: null pointer");
+    return amt_launch_rope(x, cache, y, n0, seq, n2, hd, cache_half, (hipStream_t)stream);
+}
+
+static AttnParams blh_params(const float* q, const float* k, const float* v, float* o, int B, int H, int Lq, int Lk, int hd) {
+    AttnParams a{};
+    const size_t E = (size_t)H * hd;
+    a.q = q; a.k = k; a.v = v; a.o = o;
+    a.q_bs = (size_t)Lq * E; a.k_bs = a.v_bs = (size_t)Lk * E; a.o_bs = (size_t)Lq * E;
+    a.q_hs = a.k_hs = a.v_hs = a.o_hs = hd;
+    a.q_ls = a.k_ls = a.v_ls = a.o_ls = E;
+    a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.hd = hd; a.kv_group = 1;
+    return a;
+}
+
+extern "C" int32_t amt_rpr_attn_fwd(const float* q, const float* k, const float* v, const float* Er, float* o,
+                                    int32_t B, int32_t H, int32_t L, int32_t hd, int32_t er_len, void* stream) {
+    AMT_CHECK_ARG(q && k && v && Er && o, "amt_rpr_attn_fwd: null pointer");
+    AttnParams a = blh_params(q, k, v, o, B, H, L, L, hd);
+    a.causal = 1; a.Er = Er; a.er_len = er_len;
+    return amt_launch_attn_prefill(a, (hipStream_t)stream);
+}
+
+extern "C" int32_t amt_cross_attn_fwd(const float* q, const float* k, const float* v, float* o,
+                                      int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd, int32_t causal, void* stream) {
+    AMT_CHECK_ARG(q && k && v && o, "amt_cross_attn_fwd: null pointer");
+    AttnParams a = blh_params(q, k, v, o, B, H, Lq, Lk, hd);
+    a.causal = causal;
+    return amt_launch_attn_prefill(a, (hipStream_t)stream);
+}
+
+extern "C" int32_t amt_attn_decode_fwd(const float* q, const float* kcache, const float* vcache, const float* Er, float* o,
+                                       int32_t B, int32_t H, int32_t hd, int32_t cap, int32_t pos, int32_t er_len, void* stream) {
+    AMT_CHECK_ARG(q && kcache && vcache && o, "amt_attn_decode_fwd: null pointer");
+    AMT_CHECK_ARG(pos >= 0 && pos < cap, "amt_attn_decode_fwd: pos=%d outside 0..%d", pos, cap - 1);
+    AttnDecodeParams a{};
+    a.q = q; a.k = kcache; a.v = vcache; a.o = o; a.B = B; a.H = H; a.hd = hd; a.cap = cap;
+    a.n_keys = pos + 1; a.Er = Er; a.er_len = er_len;
+    return amt_launch_attn_decode(a, (hipStream_t)stream);
+}
+
+extern "C" int32_t amt_decode_linear_fwd(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b,
+                                         const float* resid, float* y, float* xn_out, float* w_packed_scratch,
+                                         int32_t B, int32_t N, int32_t K, int32_t relu, float eps, void* stream) {
+    AMT_CHECK_ARG(x && w && y && w_packed_scratch, "amt_decode_linear_fwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    int32_t rc = amt_launch_pack_weight(w, w_packed_scratch, N, K, s);
+    if (rc) return rc;
+    DecodeGemmParams g{};
+    g.x = x; g.ldx = K; g.Wp = w_packed_scratch; g.bias = bias; g.B = B; g.N = N; g.K = K;
+    g.ln_w = ln_w; g.ln_b = ln_b; g.xn = xn_out; g.eps = eps; g.resid = resid; g.ldr = N; g.relu = relu;
+    g.scale = 1.f; g.y = y; g.ldy = N;
+    return amt_launch_decode_gemm(g, s);
+}

@@ -1,0 +1,124 @@
+// Single-query attention for the autoregressive decode step (HBM-bound K/V streaming).
+//
+// One 256-thread workgroup per (clip, head).  The head's K and V rows ([cap][hd] fp32, contiguous)
+// are streamed straight to registers with 16-byte lanes: hd/4 lanes cover one key row, so one
+// wave-instruction fetches 64/(hd/4) whole rows = 1 KiB fully coalesced.  Each lane group keeps an
+// online-softmax state (m, l, o[4]) for the keys it has seen; groups and waves are merged once at
+// the end (shuffles, then LDS).  No score row is ever materialised.
+//
+// Relative-position self-attention (model/rpr.py:391-394 in closed form): for the
+// query at position t and key j the score is q.k_j + q.Er[er_len-1-(t-j)], i.e. q.(k_j + e_j) with
+// the Er row read from L2 (the table is shared by every clip and head of a layer).
+// Cross-attention (torch MultiheadAttention at model/rpr.py:62-63) is the same kernel with Er=null
+// and a fixed key count.
+#include "amt_common.h"
+#include "kernels.h"
+
+namespace {
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
+    constexpr int LPK = HD / 4;          // lanes per key row
+    constexpr int KPW = 64 / LPK;        // keys per wave-instruction
+    constexpr int UNROLL = 4;
+    __shared__ float sm_m[4], sm_l[4];
+    __shared__ __attribute__((aligned(16))) float sm_o[4][HD];
+
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane % LPK, sub = lane / LPK;
+    const int t = p.pos ? *p.pos : (p.n_keys - 1);
+    const int n_keys = t + 1;
+
+    const float4 q4 = ld4(p.q + ((size_t)b * p.H + h) * HD + c * 4);
+    const float* kb = p.k + ((size_t)b * p.H + h) * p.cap * HD + c * 4;
+    const float* vb = p.v + ((size_t)b * p.H + h) * p.cap * HD + c * 4;
+    const float* eb = p.Er ? p.Er + (size_t)(p.er_len - 1 - t) * HD + c * 4 : nullptr;   // row of key 0
+
+    float m = -INFINITY, l = 0.f;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // wave w takes key groups w, w+4, ...; each iteration covers UNROLL groups of KPW keys
+    for (int j0 = wave * KPW; j0 < n_keys; j0 += 4 * KPW * UNROLL) {
+        float4 kk[UNROLL], vv[UNROLL], ee[UNROLL];
+        bool ok[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int j = j0 + u * 4 * KPW + sub;
+            ok[u] = j < n_keys;
+            const int jj = ok[u] ? j : 0;
+            kk[u] = ld4(kb + (size_t)jj * HD);
+            vv[u] = ld4(vb + (size_t)jj * HD);
+            if (eb) ee[u] = ld4(eb + (size_t)jj * HD);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            float4 k4 = kk[u];
+            if (eb) { k4.x += ee[u].x; k4.y += ee[u].y; k4.z += ee[u].z; k4.w += ee[u].w; }
+            float s = q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
+            s = group_sum<LPK>(s);
+            if (ok[u]) {
+                const float mn = fmaxf(m, s);
+                const float alpha = __expf(m - mn), pj = __expf(s - mn);
+                l = l * alpha + pj;
+                o.x = o.x * alpha + pj * vv[u].x; o.y = o.y * alpha + pj * vv[u].y;
+                o.z = o.z * alpha + pj * vv[u].z; o.w = o.w * alpha + pj * vv[u].w;
+                m = mn;
+            }
+        }
+    }
+
+    // merge the KPW lane groups of the wave (lanes with equal c)
+#pragma unroll
+    for (int off = LPK; off < 64; off <<= 1) {
+        const float m2 = __shfl_xor(m, off, 64), l2 = __shfl_xor(l, off, 64);
+        float4 o2;
+        o2.x = __shfl_xor(o.x, off, 64); o2.y = __shfl_xor(o.y, off, 64);
+        o2.z = __shfl_xor(o.z, off, 64); o2.w = __shfl_xor(o.w, off, 64);
+        const float mn = fmaxf(m, m2);
+        const float a1 = (m == -INFINITY) ? 0.f : __expf(m - mn);
+        const float a2 = (m2 == -INFINITY) ? 0.f : __expf(m2 - mn);
+        l = l * a1 + l2 * a2;
+        o.x = o.x * a1 + o2.x * a2; o.y = o.y * a1 + o2.y * a2;
+        o.z = o.z * a1 + o2.z * a2; o.w = o.w * a1 + o2.w * a2;
+        m = mn;
+    }
+    if (sub == 0) {
+        if (c == 0) { sm_m[wave] = m; sm_l[wave] = l; }
+        st4(&sm_o[wave][c * 4], o);
+    }
+    __syncthreads();
+    if (wave == 0 && sub == 0) {
+        float mn = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
+        float lt = 0.f;
+        float4 ot = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float a = (sm_m[w] == -INFINITY) ? 0.f : __expf(sm_m[w] - mn);
+            const float4 ow = ld4(&sm_o[w][c * 4]);
+            lt += sm_l[w] * a;
+            ot.x += ow.x * a; ot.y += ow.y * a; ot.z += ow.z * a; ot.w += ow.w * a;
+        }
+        const float inv = 1.0f / lt;
+        ot.x *= inv; ot.y *= inv; ot.z *= inv; ot.w *= inv;
+        st4(p.o + ((size_t)b * p.H + h) * HD + c * 4, ot);
+    }
+}
+
+}  // namespace
+
+int32_t amt_launch_attn_decode(const AttnDecodeParams& p, hipStream_t stream) {
+    AMT_CHECK_ARG(p.B > 0 && p.H > 0 && p.cap > 0, "attn_decode: bad shape B=%d H=%d cap=%d", p.B, p.H, p.cap);
+    AMT_CHECK_ARG(p.pos != nullptr || (p.n_keys > 0 && p.n_keys <= p.cap), "attn_decode: n_keys=%d outside (0,%d]", p.n_keys, p.cap);
+    AMT_CHECK_ARG(p.Er == nullptr || p.er_len >= p.cap, "attn_decode: er_len=%d smaller than the key capacity %d", p.er_len, p.cap);
+    dim3 grid(p.H, p.B);
+    switch (p.hd) {
+        case 16: hipLaunchKernelGGL(attn_decode_kernel<16>, grid, dim3(256), 0, stream, p); break;
+        case 32: hipLaunchKernelGGL(attn_decode_kernel<32>, grid, dim3(256), 0, stream, p); break;
+        case 64: hipLaunchKernelGGL(attn_decode_kernel<64>, grid, dim3(256), 0, stream, p); break;
+        case 128: hipLaunchKernelGGL(attn_decode_kernel<128>, grid, dim3(256), 0, stream, p); break;
+        default: AMT_CHECK_ARG(false, "attn_decode: head_dim %d not in {16,32,64,128}", p.hd);
+    }
+    AMT_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,230 @@
+// Flash-style fp32 attention on the CDNA4 matrix cores for the teacher-forced / encoder paths:
+//   O = softmax(Q K^T (+ skewed relative-position bias) (+ causal mask)) V      per (clip, head)
+// without materialising the L x L scores the reference builds (model/rpr.py:387-414) or the
+// (B*H, L, L) skew temporaries of model/rpr.py:439-455.
+//
+// Workgroup = 4 waves = 128 query rows of one (clip, head); each wave owns 32 rows.  Keys/values
+// are visited in tiles of 32 staged in LDS ([32][hd+4] floats -> conflict-free ds_read_b128).
+// Everything is computed TRANSPOSED so the softmax row reduction never crosses lanes:
+//   S^T[key][query] = K . Q^T     v_mfma_f32_32x32x2_f32, A = K tile (LDS), B = Q^T (registers)
+// puts one query per lane (column) and its 32 keys in 16 registers x 2 lane halves; the running
+// max / sum and the rescale of O^T[d][query] are then per-lane scalars, and P^T is already in the
+// B-operand layout of the second product
+//   O^T[d][query] += V^T . P^T    A = V^T read from the LDS V tile, B = P^T accumulator registers.
+//
+// Relative positions (bias[i][j] = q_i . Er[er_len-1-(i-j)], j <= i): per tile the
+// 63 distinct distances i-j form a band; R^T[m][query] = Er_band . Q^T is two more MFMA tiles
+// (A = Er rows straight from L2), written to a per-wave LDS scratch and read back along the skew
+// diagonal m = (i - j) - rel_min.
+#include "amt_common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int QB = 128;      // query rows per workgroup
+constexpr int KT = 32;       // keys per tile
+
+template <int HD, bool RPR>
+__global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
+    constexpr int LD = HD + 4;
+    constexpr int NS = HD / 8;           // ds_read_b128 k-groups per operand row
+    constexpr int ND = HD / 32;          // 32-wide d tiles of O^T
+    constexpr int SCR = 32 * 65 > 32 * (HD + 1) ? 32 * 65 : 32 * (HD + 1);
+    __shared__ __attribute__((aligned(16))) float Ks[KT * LD];
+    __shared__ __attribute__((aligned(16))) float Vs[KT * LD];
+    __shared__ __attribute__((aligned(16))) float scr_all[4 * SCR];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int qblk = gridDim.x - 1 - blockIdx.x;        // heavy (late) causal blocks first
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int hk = h / p.kv_group;
+    const int I0 = qblk * QB, i0 = I0 + wave * 32, iq = i0 + li;
+    float* scr = scr_all + wave * SCR;
+
+    const float* qp = p.q + (size_t)b * p.q_bs + (size_t)h * p.q_hs;
+    const float* kp = p.k + (size_t)b * p.k_bs + (size_t)hk * p.k_hs;
+    const float* vp = p.v + (size_t)b * p.v_bs + (size_t)hk * p.v_hs;
+
+    // Q^T fragments: qreg[4s+e] = Q[iq][8s + 4*lh + e]
+    float qreg[HD / 2];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        float4 t = (iq < p.Lq) ? ld4(qp + (size_t)iq * p.q_ls + 8 * s + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
+        qreg[4 * s + 0] = t.x; qreg[4 * s + 1] = t.y; qreg[4 * s + 2] = t.z; qreg[4 * s + 3] = t.w;
+    }
+
+    f32x16 oacc[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    int k_end = p.Lk;
+    if (p.causal) k_end = min(p.Lk, I0 + QB);
+    const int n_tiles = (k_end + KT - 1) / KT;
+
+    // K/V tile staging: 32 rows x HD/4 float4 per tensor over 256 threads
+    constexpr int F4_ROW = HD / 4, F4_TILE = KT * F4_ROW, PER_T = (F4_TILE + 255) / 256;
+    float4 kst[PER_T], vst[PER_T];
+    auto gload = [&](int j0) {
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int f = tid + i * 256;
+            const int r = f / F4_ROW, c = (f - r * F4_ROW) * 4;
+            const int j = j0 + r;
+            const bool ok = (f < F4_TILE) && (j < p.Lk);
+            kst[i] = ok ? ld4(kp + (size_t)j * p.k_ls + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            vst[i] = ok ? ld4(vp + (size_t)j * p.v_ls + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int f = tid + i * 256;
+            if (f < F4_TILE) {
+                const int r = f / F4_ROW, c = (f - r * F4_ROW) * 4;
+                st4(&Ks[r * LD + c], kst[i]);
+                st4(&Vs[r * LD + c], vst[i]);
+            }
+        }
+    };
+
+    gload(0);
+    for (int kt = 0; kt < n_tiles; ++kt) {
+        const int j0 = kt * KT;
+        __syncthreads();                 // previous tile fully consumed
+        lstore();
+        __syncthreads();
+        if (kt + 1 < n_tiles) gload(j0 + KT);
+        if (p.causal && j0 > i0 + 31) continue;          // whole tile above this wave's diagonal
+
+        // ---- S^T = K . Q^T ----
+        f32x16 sacc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float4 a = ld4(&Ks[li * LD + 8 * s + 4 * lh]);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * s + 0], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * s + 1], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * s + 2], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * s + 3], sacc, 0, 0, 0);
+        }
+
+        // ---- relative-position band: R^T[m][query] = Er[er_len-1-(rel_min+m)] . q ----
+        if (RPR) {
+            const int rel_min = i0 - j0 - 31;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                int row = p.er_len - 1 - (rel_min + mt * 32 + li);
+                row = max(0, min(p.er_len - 1, row));      // out-of-band rows belong to masked pairs
+                const float* ep = p.Er + (size_t)row * HD + 4 * lh;
+                float4 ef[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) ef[s] = ld4(ep + 8 * s);
+                f32x16 racc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) racc[e] = 0.f;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    racc = __builtin_amdgcn_mfma_f32_32x32x2f32(ef[s].x, qreg[4 * s + 0], racc, 0, 0, 0);
+                    racc = __builtin_amdgcn_mfma_f32_32x32x2f32(ef[s].y, qreg[4 * s + 1], racc, 0, 0, 0);
+                    racc = __builtin_amdgcn_mfma_f32_32x32x2f32(ef[s].z, qreg[4 * s + 2], racc, 0, 0, 0);
+                    racc = __builtin_amdgcn_mfma_f32_32x32x2f32(ef[s].w, qreg[4 * s + 3], racc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    scr[li * 65 + m] = racc[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int krow = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                sacc[e] += scr[li * 65 + (li - krow + 31)];
+            }
+        }
+
+        // ---- mask + online softmax (one query per lane, keys split over the two lane halves) ----
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int j = j0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (j >= p.Lk || (p.causal && j > iq)) sacc[e] = -INFINITY;
+            tmax = fmaxf(tmax, sacc[e]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __expf(m_run - m_use);
+        float psum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            sacc[e] = __expf(sacc[e] - m_use);
+            psum += sacc[e];
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
+
+        // ---- O^T += V^T . P^T : k-step e pairs key krow(e,0) (lanes 0-31) with krow(e,1) ----
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int krow = (e & 3) + 8 * (e >> 2) + 4 * lh;
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt) {
+                const float a = Vs[krow * LD + dt * 32 + li];
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, sacc[e], oacc[dt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- normalise, transpose through the wave's scratch, store rows coalesced ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = (l_tot > 0.f) ? 1.0f / l_tot : 0.f;
+    __syncthreads();                     // all waves are done with their scratch as R band
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int dd = dt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            scr[li * (HD + 1) + dd] = oacc[dt][e] * inv;
+        }
+    float* op = p.o + (size_t)b * p.o_bs + (size_t)h * p.o_hs;
+    for (int r = 0; r < 32; ++r) {
+        const int i = i0 + r;
+        if (i >= p.Lq) break;
+        for (int c = lane; c < HD; c += 64) op[(size_t)i * p.o_ls + c] = scr[r * (HD + 1) + c];
+    }
+}
+
+template <int HD>
+int32_t launch_hd(const AttnParams& p, hipStream_t stream) {
+    dim3 grid(cdiv(p.Lq, QB), p.H, p.B);
+    if (p.Er) hipLaunchKernelGGL((attn_prefill_kernel<HD, true>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((attn_prefill_kernel<HD, false>), grid, dim3(256), 0, stream, p);
+    return 0;
+}
+
+}  // namespace
+
+int32_t amt_launch_attn_prefill(const AttnParams& p, hipStream_t stream) {
+    AMT_CHECK_ARG(p.B > 0 && p.H > 0 && p.Lq > 0 && p.Lk > 0, "attn_prefill: bad shape");
+    AMT_CHECK_ARG(p.kv_group >= 1 && p.H % p.kv_group == 0, "attn_prefill: bad kv_group %d", p.kv_group);
+    AMT_CHECK_ARG(p.Er == nullptr || (p.causal && p.Lq == p.Lk && p.Lq <= p.er_len),
+                  "attn_prefill: relative positions need causal self-attention with L=%d <= er_len=%d", p.Lq, p.er_len);
+    AMT_CHECK_ARG(p.q_ls % 4 == 0 && p.k_ls % 4 == 0 && p.v_ls % 4 == 0, "attn_prefill: row strides must be multiples of 4 floats");
+    switch (p.hd) {
+        case 32: launch_hd<32>(p, stream); break;
+        case 64: launch_hd<64>(p, stream); break;
+        case 128: launch_hd<128>(p, stream); break;
+        default: AMT_CHECK_ARG(false, "attn_prefill: head_dim %d not in {32,64,128}", p.hd);
+    }
+    AMT_LAUNCH_CHECK();
+    return 0;
+}

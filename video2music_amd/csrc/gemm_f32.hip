@@ -1,0 +1,154 @@
+// fp32 GEMM on the CDNA4 matrix cores:  C[M,N] = epilogue(A[M,K] . W[N,K]^T)
+//
+// Both operands are K-contiguous (activations row-major, weights in torch's nn.Linear (out,in)
+// layout), so one kernel serves every dense projection of the AMT encoder / prefill path
+// (Linear_vis, packed in-proj, out-proj, FFN, cross K/V projection, Wout).
+//
+// Tiling (gfx950): 128x128 output tile per 256-thread workgroup, 4 waves as 2x2, each wave a
+// 64x64 sub-tile = 2x2 v_mfma_f32_32x32x2_f32 accumulators (exact fp32, k-ordered fma chain).
+// K is consumed 32 at a time through a double-buffered LDS image [128][36] (row stride 144 B, so
+// a ds_read_b128 lane group touches 16 distinct 16-B bank slots).  One ds_read_b128 per operand
+// fragment feeds 4 MFMAs: lane (r, h) holds k = k0+4h+e for e=0..3, MFMA e then sums k0+e (h=0)
+// and k0+4+e (h=1) -- any pairing is legal as long as A and B use the same one.
+#include "amt_common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, LDS_LD = BK + 4;   // floats
+
+struct Frag4 { float4 v[4]; };
+
+__device__ __forceinline__ void store_out(const GemmParams& p, int row, int col, float v) {
+    if (row >= p.M || col >= p.N) return;
+    if (p.bias) v += p.bias[col];
+    if (col < p.scale_cols) v *= p.scale;
+    if (p.silu_mul) {
+        const float g = p.silu_mul[(size_t)row * p.ld_silu + col];
+        v *= g / (1.0f + __expf(-g));
+    }
+    if (p.rowadd) v += p.rowadd[(size_t)(row % p.rowadd_period) * p.N + col];
+    if (p.resid) v += p.resid[(size_t)row * p.ldr + col];
+    if (p.relu) v = fmaxf(v, 0.f);
+    if (p.head_split == 0) {
+        p.C[(size_t)row * p.ldc + col] = v;
+    } else {
+        // row = b*seq + s, col = part*d + h*hd + c  ->  out[part][b][h][s][c]
+        int b = row / p.hs_seq, s = row - b * p.hs_seq;
+        int part = col / p.hs_d, cc = col - part * p.hs_d;
+        int h = cc / p.hs_hd, c = cc - h * p.hs_hd;
+        size_t off = (size_t)part * p.hs_part_stride +
+                     (((size_t)b * p.hs_heads + h) * p.hs_seq_cap + s) * p.hs_hd + c;
+        p.C[off] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][BM * LDS_LD];   // [buf][A|W][row][k]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // XCD-aware tile order: consecutive tiles along N share the A panel, keep them on one XCD
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int ntiles = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    if (p.tile_group) {              // grouped mode: per-tile expert weights
+        const int g = p.tile_group[tm];
+        if (g < 0) return;
+        p.W += (size_t)g * p.w_group_stride;
+        if (p.bias) p.bias += (size_t)g * p.bias_group_stride;
+    }
+
+    // staging: 256 threads x 4 passes x float4 cover a 128x32 tile (8 float4 per row)
+    const int srow = tid >> 3, scol = (tid & 7) * 4;
+    Frag4 ra, rw;
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = srow + i * 32;
+            int gm = m0 + r, gn = n0 + r;
+            int am = gm;
+            if (p.a_gather) am = (gm < p.M) ? p.a_gather[gm] : -1;
+            ra.v[i] = (gm < p.M && am >= 0) ? ld4(p.A + (size_t)am * p.lda + k0 + scol) : make_float4(0, 0, 0, 0);
+            rw.v[i] = (gn < p.N) ? ld4(p.W + (size_t)gn * p.ldw + k0 + scol) : make_float4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = srow + i * 32;
+            st4(&lds[buf][0][r * LDS_LD + scol], ra.v[i]);
+            st4(&lds[buf][1][r * LDS_LD + scol], rw.v[i]);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int nk = p.K / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+        const float* la = &lds[cur][0][(wr * 64 + fr) * LDS_LD + fh * 4];
+        const float* lw = &lds[cur][1][(wc * 64 + fr) * LDS_LD + fh * 4];
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 8) {
+            float4 a0 = ld4(la + kk), a1 = ld4(la + 32 * LDS_LD + kk);
+            float4 b0 = ld4(lw + kk), b1 = ld4(lw + 32 * LDS_LD + kk);
+            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv0[e], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv1[e], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv0[e], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv1[e], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) {
+            lstore(cur ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // C/D layout of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                int row = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                int col = n0 + wc * 64 + j * 32 + fr;
+                store_out(p, row, col, acc[i][j][e]);
+            }
+}
+
+}  // namespace
+
+int32_t amt_launch_gemm(const GemmParams& p, hipStream_t stream) {
+    AMT_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
+    AMT_CHECK_ARG(p.K % BK == 0, "gemm: K=%d must be a multiple of %d (pad the operands)", p.K, BK);
+    AMT_CHECK_ARG(p.lda % 4 == 0 && p.ldw % 4 == 0, "gemm: leading dimensions must be multiples of 4 floats");
+    AMT_CHECK_ARG(p.lda >= p.K && p.ldw >= p.K, "gemm: leading dimension smaller than K");
+    AMT_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0, "gemm: operands must be 16-byte aligned");
+    const int ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(ntiles), dim3(256), 0, stream, p);
+    AMT_LAUNCH_CHECK();
+    return 0;
+}

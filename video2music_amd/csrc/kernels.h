@@ -1,0 +1,120 @@
+// Internal launcher declarations shared by the C-ABI layer (amt_api.hip) and the kernel files.
+#pragma once
+#include "amt_common.h"
+
+// ---------------- dense GEMM (gemm_f32.hip) ----------------
+struct GemmParams {
+    const float* A; int lda;        // [M][K] activations
+    const float* W; int ldw;        // [N][K] weights (nn.Linear layout)
+    float* C; int ldc;              // [M][N] output (plain mode)
+    int M, N, K;
+    const float* bias;              // [N] or null
+    const float* resid; int ldr;    // [M][N] residual added after bias/scale, or null
+    const float* rowadd; int rowadd_period;   // [period][N] row-periodic addend (positional encoding), or null
+    float scale; int scale_cols;    // columns [0,scale_cols) are multiplied by scale after the bias (q * hd^-0.5)
+    int relu;
+    // head-split store: row=b*seq+s, col=part*d+h*hd+c -> C[part*part_stride + ((b*heads+h)*seq_cap+s)*hd+c]
+    int head_split, hs_seq, hs_seq_cap, hs_d, hs_hd, hs_heads;
+    size_t hs_part_stride;
+    // grouped (mixture-of-experts) mode: the 128-row tile tm uses weight group tile_group[tm] (< 0: tile unused)
+    const int* tile_group; size_t w_group_stride, bias_group_stride;
+    const int* a_gather;            // A row of output row m is a_gather[m] (< 0: zero row), or null
+    const float* silu_mul; int ld_silu;   // v *= silu(silu_mul[row][col]) after the bias (GLU gate), or null
+};
+static inline GemmParams gemm_params(const float* A, int lda, const float* W, int ldw, float* C, int ldc,
+                                     int M, int N, int K, const float* bias) {
+    GemmParams p{};
+    p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.bias = bias;
+    p.scale = 1.f; p.rowadd_period = 1;
+    return p;
+}
+int32_t amt_launch_gemm(const GemmParams& p, hipStream_t stream);
+
+// ---------------- normalisation / elementwise (norm.hip) ----------------
+// y = LayerNorm(x (+ resid)) * w + b ; optional second LayerNorm (w2,b2) applied on top (decoder.norm)
+int32_t amt_launch_layernorm(const float* x, const float* resid, const float* w, const float* b,
+                             const float* w2, const float* b2, float* y, int rows, int dim, float eps,
+                             hipStream_t stream);
+int32_t amt_launch_rmsnorm(const float* x, const float* w, float* y, int rows, int dim, float eps, hipStream_t stream);
+// rotary embedding on interleaved pairs: x viewed as [n0][seq][n2][hd], cache [>=seq][cache_half][2];
+// reproduces the reference's view(-1, seq, 1, hd/2, 2)[:n0] reinterpretation of the cache
+int32_t amt_launch_rope(const float* x, const float* cache, float* y, int n0, int seq, int n2, int hd,
+                        int cache_half, hipStream_t stream);
+// vf_concat[b*S+s][0:Fpad] = [sem | scene | motion | emotion | 0-pad]
+int32_t amt_launch_concat_features(const float* sem, int sem_dim, const float* scene, const float* motion, int motion_dim,
+                                   const float* emotion, int emo_dim, float* out, int rows, int ld_out, hipStream_t stream);
+// xf[b*L+l] = PR[root] + PA[attr] + key[b]*wkey + bias + pe[l]
+int32_t amt_launch_chord_embed(const int64_t* root, const int64_t* attr, const float* key, const float* PR, const float* PA,
+                               const float* wkey, const float* bias, const float* pe, float* out,
+                               int B, int L, int d, hipStream_t stream);
+
+// ---------------- attention, prefill (attn_prefill.hip) ----------------
+struct AttnParams {
+    const float* q; const float* k; const float* v; float* o;
+    // element strides: tensor[b][h][l][c] = base + b*bs + h*hs + l*ls + c
+    size_t q_bs, q_hs, q_ls, k_bs, k_hs, k_ls, v_bs, v_hs, v_ls, o_bs, o_hs, o_ls;
+    int B, H, Lq, Lk, hd;
+    int causal;                 // keys j > query i masked
+    const float* Er; int er_len;   // relative position table [er_len][hd] or null
+    int kv_group;               // query head h uses kv head h / kv_group (GQA); 1 for MHA
+    float mask_value;           // -inf (additive mask semantics) or finfo.min (masked_fill semantics)
+};
+int32_t amt_launch_attn_prefill(const AttnParams& p, hipStream_t stream);
+
+// ---------------- attention, decode (attn_decode.hip) ----------------
+struct AttnDecodeParams {
+    const float* q;             // [B][H*hd] (already scaled)
+    const float* k; const float* v;   // [B][H][cap][hd]
+    float* o;                   // [B][H*hd]
+    int B, H, hd, cap;
+    const int* pos;             // device: index of the query token (keys 0..pos); null -> n_keys fixed
+    int n_keys;                 // used when pos == null (cross-attention: S)
+    const float* Er; int er_len;
+};
+int32_t amt_launch_attn_decode(const AttnDecodeParams& p, hipStream_t stream);
+
+// ---------------- decode-step skinny GEMM (decode_gemm.hip) ----------------
+// packed weight: tiles of 16(n) x 16(k): P[((nt*(K/16)+kt)*64 + lane)*4 + e] = W[nt*16+(lane&15)][kt*16+4*(lane>>4)+e]
+int32_t amt_launch_pack_weight(const float* W, float* P, int N, int K, hipStream_t stream);
+struct DecodeGemmParams {
+    const float* x; int ldx;    // [B][K] input rows (pre-LN sum when ln_w != null)
+    const float* Wp;            // packed weight
+    const float* bias;          // [N]
+    int B, N, K;
+    // LayerNorm prologue (optional, up to two stacked LNs); normalised rows are also written to xn (ld = K)
+    const float* ln_w; const float* ln_b; const float* ln2_w; const float* ln2_b; float* xn; float eps;
+    // epilogue
+    int mode;                   // 0: y = acc+bias (+resid) (relu) ; 1: packed-QKV split into q / K-cache / V-cache
+    const float* resid; int ldr;
+    int relu;
+    float scale; int scale_cols;
+    float* y; int ldy;
+    // mode 1
+    float* kcache; float* vcache; int H, hd, cap; const int* pos; int d;
+};
+int32_t amt_launch_decode_gemm(const DecodeGemmParams& p, hipStream_t stream);
+
+// ---------------- sampling head (sample.hip) ----------------
+struct SampleParams {
+    const float* u; int ldu;        // [B][d] pre-LN sum of the last decoder layer
+    const float* ln_w; const float* ln_b;     // last layer norm3
+    const float* fn_w; const float* fn_b;     // decoder.norm
+    const float* Wout; const float* bout;     // [159][d], [159]
+    float eps;
+    int B, d;
+    int64_t* tokens; int64_t* roots; int64_t* attrs; int T;   // [B][T] sequences (device)
+    int* pos;                        // device step counter (input position); advanced by the last block
+    unsigned* ticket;                // device arrival counter (zero between launches)
+    int n_primer;                    // positions < n_primer are given, not sampled
+    int beam;                        // 0: feedback greedy (G2), 1: verbatim top-1 (G1)
+    int max_conseq_N, max_conseq_chord;
+    float* logits_out;               // optional [T][B][159] (row pos)
+    float* probs_out;                // optional [B][157] decision distribution of this step
+    // next-step input embedding
+    const float* key; const float* PR; const float* PA; const float* wkey; const float* cbias; const float* pe;
+    float* x_next;                   // [B][d]
+    int sample_external;             // 1: do not pick a token (host samples from probs_out), only write probs
+};
+int32_t amt_launch_sample(const SampleParams& p, hipStream_t stream);
+// writes x_next for position *pos from the token sequences (start of generate / external sampling)
+int32_t amt_launch_embed_step(const SampleParams& p, int advance, hipStream_t stream);

@@ -1,0 +1,211 @@
+// Mixture-of-experts gated FFN (model/moe.py:36-49 GLUExpert, :150-200 MoELayer, :202-302
+// SharedMoELayer; eval mode) and MultiheadGQA (model/grouped_query_attention.py:286-358) as
+// compositions of the library's kernels.
+//
+// MoE: instead of the reference's python loop over experts with torch.where gather / scatter
+//   router (one wave per token: 8 dot products, top-2, softmax)  ->  plan (sort the 2*n_tok
+//   assignments by expert into 128-row aligned segments)  ->  three GROUPED fp32-MFMA GEMMs whose
+//   row tiles pick their expert's weights (gate, up * silu(gate), down)  ->  combine (each token
+//   sums its two expert rows, lower expert id first, + shared expert / k).
+// Every step is deterministic: no float atomics, fixed summation order per token.
+#include "../../include/amt_hip.h"
+#include "amt_common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int TILE = 128;
+
+__global__ __launch_bounds__(256) void moe_route_kernel(const float* __restrict__ x, const float* __restrict__ gw,
+                                                        const float* __restrict__ gb, int n_tok, int d, int n_exp,
+                                                        int* __restrict__ idx, float* __restrict__ wts) {
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= n_tok) return;
+    float best0 = -INFINITY, best1 = -INFINITY;
+    int i0 = 0, i1 = 0;
+    for (int e = 0; e < n_exp; ++e) {
+        float s = 0.f;
+        for (int c = lane * 4; c < d; c += 256) {
+            const float4 a = ld4(x + (size_t)tok * d + c), w = ld4(gw + (size_t)e * d + c);
+            s += a.x * w.x + a.y * w.y + a.z * w.z + a.w * w.w;
+        }
+        s = wave_sum(s) + (gb ? gb[e] : 0.f);
+        if (s > best0) { best1 = best0; i1 = i0; best0 = s; i0 = e; }
+        else if (s > best1) { best1 = s; i1 = e; }
+    }
+    if (lane == 0) {
+        // softmax over the two selected logits (moe.py:190,288), largest first like torch.topk
+        const float e1 = __expf(best1 - best0);
+        const float inv = 1.0f / (1.0f + e1);
+        idx[tok * 2] = i0; idx[tok * 2 + 1] = i1;
+        wts[tok * 2] = inv; wts[tok * 2 + 1] = e1 * inv;
+    }
+}
+
+// single workgroup: counts, 128-aligned exclusive scan, stable slot assignment in token order
+__global__ __launch_bounds__(1024) void moe_plan_kernel(const int* __restrict__ idx, int n_tok, int n_exp,
+                                                        int* __restrict__ perm, int* __restrict__ slot_pos,
+                                                        int* __restrict__ tile_group, int Mp) {
+    __shared__ int cnt[64], off[65];
+    const int tid = threadIdx.x;
+    if (tid < 64) cnt[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < 2 * n_tok; i += 1024) atomicAdd(&cnt[idx[i]], 1);
+    for (int i = tid; i < Mp; i += 1024) perm[i] = -1;
+    for (int i = tid; i < Mp / TILE; i += 1024) tile_group[i] = -1;
+    __syncthreads();
+    if (tid == 0) {
+        int o = 0;
+        for (int e = 0; e < n_exp; ++e) { off[e] = o; o += (cnt[e] + TILE - 1) / TILE * TILE; }
+        off[n_exp] = o;
+    }
+    __syncthreads();
+    for (int e = 0; e < n_exp; ++e)
+        for (int t = off[e] / TILE + tid; t < (off[e] + cnt[e] + TILE - 1) / TILE; t += 1024) tile_group[t] = e;
+    // deterministic order inside an expert: one wave places the assignments in index order; lane g
+    // carries the running count of expert g in a register (no LDS hazards)
+    if (tid < 64) {
+        int mycnt = 0;
+        for (int base = 0; base < 2 * n_tok; base += 64) {
+            const int i = base + tid;
+            const int e = i < 2 * n_tok ? idx[i] : -1;
+            for (int g = 0; g < n_exp; ++g) {
+                const unsigned long long m = __ballot(e == g);
+                const int start = __shfl(mycnt, g, 64);
+                if (e == g) {
+                    const int pos = off[g] + start + __popcll(m & ((1ull << tid) - 1));
+                    perm[pos] = i >> 1;
+                    slot_pos[i] = pos;
+                }
+                if (tid == g) mycnt += __popcll(m);
+            }
+        }
+    }
+}
+
+__global__ void moe_combine_kernel(const float* __restrict__ Y, const int* __restrict__ slot_pos,
+                                   const int* __restrict__ idx, const float* __restrict__ wts,
+                                   const float* __restrict__ shared, float shared_scale, float* __restrict__ out, int d) {
+    const int tok = blockIdx.x;
+    int a = 0, b = 1;
+    if (idx[tok * 2] > idx[tok * 2 + 1]) { a = 1; b = 0; }        // accumulate in expert-index order (moe.py:191-199)
+    const float wa = wts[tok * 2 + a], wb = wts[tok * 2 + b];
+    const float* ya = Y + (size_t)slot_pos[tok * 2 + a] * d;
+    const float* yb = Y + (size_t)slot_pos[tok * 2 + b] * d;
+    for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
+        const float4 p = ld4(ya + c), q = ld4(yb + c);
+        float4 o;
+        o.x = wa * p.x + wb * q.x; o.y = wa * p.y + wb * q.y; o.z = wa * p.z + wb * q.z; o.w = wa * p.w + wb * q.w;
+        if (shared) {
+            const float4 s = ld4(shared + (size_t)tok * d + c);
+            o.x += shared_scale * s.x; o.y += shared_scale * s.y; o.z += shared_scale * s.z; o.w += shared_scale * s.w;
+        }
+        st4(out + (size_t)tok * d + c, o);
+    }
+}
+
+inline size_t align4(size_t n) { return (n + 3) / 4 * 4; }
+
+}  // namespace
+
+extern "C" int64_t amt_moe_scratch_floats(int32_t n_tok, int32_t d, int32_t dff, int32_t n_exp) {
+    const size_t Mp = ((size_t)2 * n_tok + TILE - 1) / TILE * TILE + (size_t)TILE * n_exp;
+    // G, H : Mp x dff ; Y : Mp x d ; shared G,H : n_tok x dff ; shared Y : n_tok x d ; ints: perm, slot_pos, tile_group
+    return (int64_t)(2 * Mp * dff + Mp * d + 2 * (size_t)n_tok * dff + (size_t)n_tok * d +
+                     align4(Mp) + 3 * align4(2 * (size_t)n_tok) + align4(Mp / TILE + 1) + 64);
+}
+
+extern "C" int32_t amt_moe_fwd(const float* x, const float* gate_w, const float* gate_b,
+                               const float* w1, const float* b1, const float* wg, const float* bg, const float* w2, const float* b2,
+                               const float* sw1, const float* sb1, const float* swg, const float* sbg, const float* sw2, const float* sb2,
+                               float* out, int32_t* idx_out, float* w_out, float* scratch,
+                               int32_t n_tok, int32_t d, int32_t dff, int32_t n_exp, void* stream) {
+    AMT_CHECK_ARG(x && gate_w && w1 && wg && w2 && out && scratch, "amt_moe_fwd: null pointer");
+    AMT_CHECK_ARG(n_tok > 0 && n_exp >= 2 && n_exp <= 64, "amt_moe_fwd: need 2 <= n_experts <= 64");
+    AMT_CHECK_ARG(d % 32 == 0 && dff % 32 == 0, "amt_moe_fwd: d and d_ff must be multiples of 32");
+    hipStream_t s = (hipStream_t)stream;
+    const int Mp = (2 * n_tok + TILE - 1) / TILE * TILE + TILE * n_exp;     // multiple of the row tile
+    float* G = scratch;
+    float* Hh = G + (size_t)Mp * dff;
+    float* Y = Hh + (size_t)Mp * dff;
+    float* Gs = Y + (size_t)Mp * d;
+    float* Hs = Gs + (size_t)n_tok * dff;
+    float* Ys = Hs + (size_t)n_tok * dff;
+    int* perm = (int*)(Ys + (size_t)n_tok * d);
+    int* slot_pos = perm + align4(Mp);
+    int* tile_group = slot_pos + align4(2 * (size_t)n_tok);
+    int* idx = tile_group + align4(Mp / TILE + 1);
+    float* wts = (float*)(idx + align4(2 * (size_t)n_tok));
+    if (idx_out) idx = idx_out;
+    if (w_out) wts = w_out;
+
+    hipLaunchKernelGGL(moe_route_kernel, dim3(cdiv(n_tok, 4)), dim3(256), 0, s, x, gate_w, gate_b, n_tok, d, n_exp, idx, wts);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(moe_plan_kernel, dim3(1), dim3(1024), 0, s, idx, n_tok, n_exp, perm, slot_pos, tile_group, Mp);
+    AMT_LAUNCH_CHECK();
+    int32_t rc;
+    // gate branch: G = x_e . Wg[e]^T + bg[e]
+    GemmParams g = gemm_params(x, d, wg, d, G, dff, Mp, dff, d, bg);
+    g.a_gather = perm; g.tile_group = tile_group; g.w_group_stride = (size_t)dff * d; g.bias_group_stride = dff;
+    if ((rc = amt_launch_gemm(g, s))) return rc;
+    // up branch fused with the gate: H = (x_e . W1[e]^T + b1[e]) * silu(G)
+    GemmParams u = gemm_params(x, d, w1, d, Hh, dff, Mp, dff, d, b1);
+    u.a_gather = perm; u.tile_group = tile_group; u.w_group_stride = (size_t)dff * d; u.bias_group_stride = dff;
+    u.silu_mul = G; u.ld_silu = dff;
+    if ((rc = amt_launch_gemm(u, s))) return rc;
+    // down: Y = H . W2[e]^T + b2[e]
+    GemmParams dn = gemm_params(Hh, dff, w2, dff, Y, d, Mp, d, dff, b2);
+    dn.tile_group = tile_group; dn.w_group_stride = (size_t)d * dff; dn.bias_group_stride = d;
+    if ((rc = amt_launch_gemm(dn, s))) return rc;
+    const float* shared = nullptr;
+    if (sw1) {
+        AMT_CHECK_ARG(swg && sw2, "amt_moe_fwd: incomplete shared expert");
+        GemmParams a = gemm_params(x, d, swg, d, Gs, dff, n_tok, dff, d, sbg);
+        if ((rc = amt_launch_gemm(a, s))) return rc;
+        GemmParams b = gemm_params(x, d, sw1, d, Hs, dff, n_tok, dff, d, sb1);
+        b.silu_mul = Gs; b.ld_silu = dff;
+        if ((rc = amt_launch_gemm(b, s))) return rc;
+        GemmParams c = gemm_params(Hs, dff, sw2, dff, Ys, d, n_tok, d, dff, sb2);
+        if ((rc = amt_launch_gemm(c, s))) return rc;
+        shared = Ys;
+    }
+    hipLaunchKernelGGL(moe_combine_kernel, dim3(n_tok), dim3(128), 0, s, Y, slot_pos, idx, wts, shared, 0.5f, out, d);
+    AMT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int32_t amt_gqa_fwd(const float* query, const float* key, const float* value,
+                               const float* wq, const float* bq, const float* wk, const float* bk, const float* wv, const float* bv,
+                               const float* ln_w, const float* ln_b, const float* wo, const float* bo,
+                               float* out, float* scratch, int32_t L, int32_t S, int32_t B, int32_t E, int32_t query_heads,
+                               int32_t kv_heads, int32_t is_causal, float ln_eps, void* stream) {
+    AMT_CHECK_ARG(query && key && value && wq && wk && wv && wo && out && scratch, "amt_gqa_fwd: null pointer");
+    AMT_CHECK_ARG(query_heads > 0 && kv_heads > 0 && query_heads % kv_heads == 0 && E % query_heads == 0, "amt_gqa_fwd: bad head counts");
+    hipStream_t s = (hipStream_t)stream;
+    const int hd = E / query_heads, Ekv = hd * kv_heads;
+    float* q = scratch;                         // [L*B][E]
+    float* k = q + (size_t)L * B * E;           // [S*B][Ekv]
+    float* v = k + (size_t)S * B * Ekv;
+    float* a = v + (size_t)S * B * Ekv;         // [L*B][E] attention output, then LayerNorm in place
+    int32_t rc;
+    GemmParams gq = gemm_params(query, E, wq, E, q, E, L * B, E, E, bq);
+    gq.scale = 1.0f / sqrtf((float)hd); gq.scale_cols = E;       // query / sqrt(hd), grouped_query_attention.py:121-123
+    if ((rc = amt_launch_gemm(gq, s))) return rc;
+    if ((rc = amt_launch_gemm(gemm_params(key, E, wk, E, k, Ekv, S * B, Ekv, E, bk), s))) return rc;
+    if ((rc = amt_launch_gemm(gemm_params(value, E, wv, E, v, Ekv, S * B, Ekv, E, bv), s))) return rc;
+    // the reference reinterprets the (L,B,.) projection buffers in memory order as (B,L,.) (:316-326):
+    // batch-first strides on the same memory; the output is written transposed back as (L',B',E) (:159)
+    AttnParams p{};
+    p.q = q; p.k = k; p.v = v; p.o = a;
+    p.q_bs = (size_t)L * E; p.q_ls = E; p.q_hs = hd;
+    p.k_bs = p.v_bs = (size_t)S * Ekv; p.k_ls = p.v_ls = Ekv; p.k_hs = p.v_hs = hd;
+    p.o_bs = E; p.o_ls = (size_t)B * E; p.o_hs = hd;
+    p.B = B; p.H = query_heads; p.Lq = L; p.Lk = S; p.hd = hd; p.causal = is_causal; p.kv_group = query_heads / kv_heads;
+    if ((rc = amt_launch_attn_prefill(p, s))) return rc;
+    const float* proj_in = a;
+    if (ln_w) {
+        if ((rc = amt_launch_layernorm(a, nullptr, ln_w, ln_b, nullptr, nullptr, a, L * B, E, ln_eps, s))) return rc;
+    }
+    return amt_launch_gemm(gemm_params(proj_in, E, wo, E, out, E, L * B, E, E, bo), s);
+}

@@ -1,0 +1,242 @@
+// Output head of one decode step: final LayerNorms -> Wout -> softmax -> decision -> feedback.
+//
+// One 256-thread workgroup per clip.  Restates, on device and without host round trips, the body
+// of the reference's generate loop (model/video_music_transformer.py:1070-1131):
+//   y = softmax(logits)[:157]                      (END/PAD dropped, not renormalised, :1070-1071)
+//   beam==1 : tok = top-1(y); root/attr sequences are left at PAD                     (:1078-1084)
+//   beam==0 : y[0]=0 if max_conseq_N==0; y[prev]=0 if the last max_conseq_chord ids are equal;
+//             tok = argmax(y / sum(y))  (Categorical.sample replaced by arg-max = oracle G2);
+//             (root, attr) = (0,1) for N else ((tok-1)/13+1, (tok-1)%13+1)             (:1085-1123)
+// and then builds the next step's decoder input
+//   x[t+1] = Linear_chord([E_root[root]+E_attr[attr], key]) + pe[t+1]                  (:984-1001,1029)
+// from the tables PR = E_root.Wc[:, :d]^T, PA = E_attr.Wc[:, :d]^T precomputed at weight load.
+// The last workgroup to finish advances the device-side position counter that every kernel of
+// the captured step graph reads, so one graph replays for all steps.
+#include "amt_common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int V = 159, VP = 157;       // CHORD_SIZE, CHORD_END
+constexpr int ROOT_PAD = 14, ATTR_PAD = 15;
+
+__device__ __forceinline__ void write_next_input(const SampleParams& p, int b, int cur, int root, int attr) {
+    const float kv = p.key[b];
+    for (int c = threadIdx.x * 4; c < p.d; c += blockDim.x * 4) {
+        const float4 pr = ld4(p.PR + (size_t)root * p.d + c), pa = ld4(p.PA + (size_t)attr * p.d + c);
+        const float4 wk = ld4(p.wkey + c), bb = ld4(p.cbias + c), pp = ld4(p.pe + (size_t)cur * p.d + c);
+        float4 o;
+        o.x = ((pr.x + pa.x) + kv * wk.x + bb.x) + pp.x;
+        o.y = ((pr.y + pa.y) + kv * wk.y + bb.y) + pp.y;
+        o.z = ((pr.z + pa.z) + kv * wk.z + bb.z) + pp.z;
+        o.w = ((pr.w + pa.w) + kv * wk.w + bb.w) + pp.w;
+        st4(p.x_next + (size_t)b * p.d + c, o);
+    }
+}
+
+__device__ __forceinline__ void advance_pos(const SampleParams& p, int t) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // every block has read *pos before it takes a ticket; the last one publishes t+1
+        const unsigned n = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n == gridDim.x - 1) {
+            *p.pos = t + 1;
+            __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
+    __shared__ __attribute__((aligned(16))) float ys[1024];
+    __shared__ float logit[V + 1];
+    __shared__ int s_tok;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = p.d;
+    const int t = *p.pos, cur = t + 1;
+
+    // ---- LayerNorm(s) of the row, by wave 0 (d <= 1024: up to 4 float4 per lane) ----
+    if (wave == 0) {
+        float4 v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = (c * 64 + lane) * 4;
+            v[c] = (i < d) ? ld4(p.u + (size_t)b * p.ldu + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const float* gw = pass == 0 ? p.ln_w : p.fn_w;
+            const float* gb = pass == 0 ? p.ln_b : p.fn_b;
+            if (!gw) continue;
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s += v[c].x + v[c].y + v[c].z + v[c].w;
+            const float mean = wave_sum(s) / d;
+            float q = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int i = (c * 64 + lane) * 4;
+                if (i < d) {
+                    const float dx = v[c].x - mean, dy = v[c].y - mean, dz = v[c].z - mean, dw = v[c].w - mean;
+                    q += dx * dx + dy * dy + dz * dz + dw * dw;
+                }
+            }
+            const float rstd = 1.0f / sqrtf(wave_sum(q) / d + p.eps);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int i = (c * 64 + lane) * 4;
+                if (i < d) {
+                    const float4 g = ld4(gw + i), h = ld4(gb + i);
+                    v[c].x = (v[c].x - mean) * rstd * g.x + h.x; v[c].y = (v[c].y - mean) * rstd * g.y + h.y;
+                    v[c].z = (v[c].z - mean) * rstd * g.z + h.z; v[c].w = (v[c].w - mean) * rstd * g.w + h.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = (c * 64 + lane) * 4;
+            if (i < d) st4(&ys[i], v[c]);
+        }
+    }
+    __syncthreads();
+
+    // ---- logits = y . Wout^T + b : wave w takes rows w, w+4, ... ----
+    for (int n = wave; n < V; n += 4) {
+        float s = 0.f;
+        for (int i = lane * 4; i < d; i += 256) {
+            const float4 w = ld4(p.Wout + (size_t)n * d + i), y = ld4(&ys[i]);
+            s += w.x * y.x + w.y * y.y + w.z * y.z + w.w * y.w;
+        }
+        s = wave_sum(s);
+        if (lane == 0) logit[n] = s + p.bout[n];
+    }
+    __syncthreads();
+    if (p.logits_out)
+        for (int n = tid; n < V; n += 256) p.logits_out[((size_t)t * p.B + b) * V + n] = logit[n];
+
+    // ---- decision, by wave 0 ----
+    if (wave == 0) {
+        float x[3], pr[3];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int n = lane + 64 * k;
+            x[k] = (n < V) ? logit[n] : -INFINITY;
+            mx = fmaxf(mx, x[k]);
+        }
+        mx = wave_max(mx);
+        float se = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            pr[k] = (lane + 64 * k < V) ? __expf(x[k] - mx) : 0.f;
+            se += pr[k];
+        }
+        se = wave_sum(se);
+        int prev = -1;
+        if (p.beam == 0) {
+            if (cur >= p.max_conseq_chord && cur >= 1) {
+                prev = (int)p.tokens[(size_t)b * p.T + cur - 1];
+                for (int k = 1; k < p.max_conseq_chord; ++k)
+                    if ((int)p.tokens[(size_t)b * p.T + cur - 1 - k] != prev) prev = -1;
+            }
+        }
+        float ps = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int n = lane + 64 * k;
+            pr[k] = (n < VP) ? pr[k] / se : 0.f;               // softmax(...)[:157]
+            if (p.beam == 0) {
+                if (n == 0 && p.max_conseq_N == 0) pr[k] = 0.f;
+                if (n == prev) pr[k] = 0.f;
+            }
+            ps += pr[k];
+        }
+        ps = wave_sum(ps);
+        if (p.probs_out) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (lane + 64 * k < VP) p.probs_out[(size_t)b * VP + lane + 64 * k] = pr[k];
+        }
+        float bv = -1.f;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int n = lane + 64 * k;
+            const float pn = (p.beam == 0) ? pr[k] / ps : pr[k];   // Categorical normalises its probs
+            if (n < VP && pn > bv) { bv = pn; bi = n; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) s_tok = bi;
+    }
+    __syncthreads();
+
+    if (!p.sample_external && cur < p.T) {
+        int tok, root, attr;
+        if (cur < p.n_primer) {
+            tok = (int)p.tokens[(size_t)b * p.T + cur];
+            root = (int)p.roots[(size_t)b * p.T + cur];
+            attr = (int)p.attrs[(size_t)b * p.T + cur];
+        } else {
+            tok = s_tok;
+            if (p.beam == 0) {
+                root = tok == 0 ? 0 : (tok - 1) / 13 + 1;
+                attr = tok == 0 ? 1 : (tok - 1) % 13 + 1;
+            } else {
+                root = ROOT_PAD; attr = ATTR_PAD;
+            }
+            if (tid == 0) {
+                p.tokens[(size_t)b * p.T + cur] = tok;
+                p.roots[(size_t)b * p.T + cur] = root;
+                p.attrs[(size_t)b * p.T + cur] = attr;
+            }
+        }
+        write_next_input(p, b, cur, root, attr);
+        advance_pos(p, t);
+    }
+}
+
+// x_next for position *pos from the stored sequences (first step of generate, or after the host
+// committed an externally sampled token at position *pos + advance)
+__global__ __launch_bounds__(256) void embed_step_kernel(SampleParams p, int advance) {
+    const int b = blockIdx.x;
+    const int t = *p.pos, cur = t + advance;
+    if (cur < p.T) {
+        if (advance && p.beam == 0 && cur >= p.n_primer && threadIdx.x == 0) {
+            const int tok = (int)p.tokens[(size_t)b * p.T + cur];
+            p.roots[(size_t)b * p.T + cur] = tok == 0 ? 0 : (tok - 1) / 13 + 1;
+            p.attrs[(size_t)b * p.T + cur] = tok == 0 ? 1 : (tok - 1) % 13 + 1;
+        }
+        __syncthreads();
+        int root, attr;
+        if (advance && p.beam == 0 && cur >= p.n_primer) {
+            const int tok = (int)p.tokens[(size_t)b * p.T + cur];
+            root = tok == 0 ? 0 : (tok - 1) / 13 + 1;
+            attr = tok == 0 ? 1 : (tok - 1) % 13 + 1;
+        } else {
+            root = (int)p.roots[(size_t)b * p.T + cur];
+            attr = (int)p.attrs[(size_t)b * p.T + cur];
+        }
+        write_next_input(p, b, cur, root, attr);
+    }
+    if (advance) advance_pos(p, t);
+}
+
+}  // namespace
+
+int32_t amt_launch_sample(const SampleParams& p, hipStream_t stream) {
+    AMT_CHECK_ARG(p.B > 0 && p.d % 4 == 0 && p.d <= 1024, "sample: bad shape B=%d d=%d", p.B, p.d);
+    hipLaunchKernelGGL(sample_kernel, dim3(p.B), dim3(256), 0, stream, p);
+    AMT_LAUNCH_CHECK();
+    return 0;
+}
+
+int32_t amt_launch_embed_step(const SampleParams& p, int advance, hipStream_t stream) {
+    AMT_CHECK_ARG(p.B > 0 && p.d % 4 == 0, "embed_step: bad shape");
+    hipLaunchKernelGGL(embed_step_kernel, dim3(p.B), dim3(256), 0, stream, p, advance);
+    AMT_LAUNCH_CHECK();
+    return 0;
+}

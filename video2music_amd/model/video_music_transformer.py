@@ -1,0 +1,336 @@
+"""``VideoMusicTransformer`` — MI355X host module of the Affective Multimodal Transformer.
+
+Drop-in for the reference class of the same name (``model/video_music_transformer.py:910-1132``):
+same constructor keywords, same ``state_dict`` keys and shapes (torch's packed ``in_proj_weight``
+layout, ``Er`` per decoder layer, the two ``pe`` buffers), same ``forward`` / ``generate``
+signatures and return types.  The arithmetic runs in ``libamt_hip.so`` (hand-written gfx950 kernels
+behind the C ABI of ``include/amt_hip.h``); PyTorch only owns parameters, device buffers and
+streams.  There is no CPU path: calling ``forward``/``generate`` without the HIP library or on a
+non-GPU module raises.
+
+Differences a caller can observe, all additive:
+  * ``generate`` accepts ``sampler="categorical"`` (default; the reference's
+    ``Categorical.sample``, drawn with ``torch.multinomial`` on device) or ``"argmax"`` (the
+    deterministic feedback-greedy decode used for parity, oracle G2);
+  * ``generate_batch`` runs B clips at once (the reference is hard-wired to one clip,
+    ``:1059-1061``); per clip the result equals a B=1 ``generate``;
+  * the video encoder runs once per clip and decoding uses a KV cache — exact for this model
+    because its logits at position i do not depend on the current length.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..utilities.constants import (CHORD_ATTR_PAD, CHORD_ATTR_SIZE, CHORD_END, CHORD_PAD, CHORD_ROOT_PAD,
+                                   CHORD_ROOT_SIZE, CHORD_SIZE, IS_SEPERATED, SCENE_OFFSET_MAX)
+
+MAX_DECODE_BATCH = 32          # clips per library call; larger batches are processed in slices
+
+
+class PositionalEncoding(nn.Module):
+    """Sinusoidal table of model/positional_encoding.py:7-23 (buffer ``pe`` of shape (max_len,1,d))."""
+
+    def __init__(self, d_model, dropout=0.1, max_len=5000):
+        super().__init__()
+        self.dropout = nn.Dropout(p=dropout)
+        pe = torch.zeros(max_len, d_model)
+        position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe.unsqueeze(0).transpose(0, 1).contiguous())
+
+
+class _AttnParams(nn.Module):
+    """Parameter container with the key names of torch.nn.MultiheadAttention /
+    MultiheadAttentionRPR (model/rpr.py:112-168): in_proj_weight, in_proj_bias, [Er], out_proj.*"""
+
+    def __init__(self, d_model, head_dim, er_len=None):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d_model, d_model))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d_model))
+        if er_len is not None:
+            self.Er = nn.Parameter(torch.rand(er_len, head_dim))
+        self.out_proj = nn.Linear(d_model, d_model)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+
+
+class _EncoderLayerParams(nn.Module):
+    def __init__(self, d_model, head_dim, d_ff):
+        super().__init__()
+        self.self_attn = _AttnParams(d_model, head_dim)
+        self.linear1 = nn.Linear(d_model, d_ff)
+        self.linear2 = nn.Linear(d_ff, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+
+
+class _DecoderLayerParams(nn.Module):
+    """Keys of TransformerDecoderLayerRPR (model/rpr.py:37-53)."""
+
+    def __init__(self, d_model, head_dim, d_ff, er_len):
+        super().__init__()
+        self.self_attn = _AttnParams(d_model, head_dim, er_len)
+        self.multihead_attn = _AttnParams(d_model, head_dim)
+        self.linear1 = nn.Linear(d_model, d_ff)
+        self.linear2 = nn.Linear(d_ff, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+
+
+class _Stack(nn.Module):
+    def __init__(self, layers, d_model):
+        super().__init__()
+        self.layers = nn.ModuleList(layers)
+        self.norm = nn.LayerNorm(d_model)
+
+
+class _TransformerParams(nn.Module):
+    """Key layout of ``nn.Transformer(custom_decoder=TransformerDecoderRPR)`` as built at
+    model/video_music_transformer.py:963-971."""
+
+    def __init__(self, d_model, nhead, n_layers, d_ff, er_len):
+        super().__init__()
+        hd = d_model // nhead
+        self.encoder = _Stack([_EncoderLayerParams(d_model, hd, d_ff) for _ in range(n_layers)], d_model)
+        self.decoder = _Stack([_DecoderLayerParams(d_model, hd, d_ff, er_len) for _ in range(n_layers)], d_model)
+        for p in self.parameters():                 # nn.Transformer._reset_parameters
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    @staticmethod
+    def generate_square_subsequent_mask(sz, device=None, dtype=None):
+        return torch.triu(torch.full((sz, sz), float("-inf"), dtype=dtype or torch.float32, device=device), diagonal=1)
+
+
+class VideoMusicTransformer(nn.Module):
+    def __init__(self, n_layers=6, num_heads=8, d_model=512, dim_feedforward=1024,
+                 dropout=0.1, max_sequence_midi=2048, max_sequence_video=300,
+                 max_sequence_chord=300, total_vf_dim=0, rpr=False, scene_embed=False,
+                 chord_embed=False):
+        super().__init__()
+        if not rpr:
+            raise NotImplementedError("video2music_amd implements the rpr=True AMT (the configuration the reference "
+                                      "ships and BASELINE.json names); rpr=False selects torch's stock decoder")
+        if scene_embed or chord_embed:
+            raise NotImplementedError("scene_embed / chord_embed are outside the hot path (SURVEY.md §2 row 28)")
+        self.nlayers = n_layers
+        self.nhead = num_heads
+        self.d_model = d_model
+        self.d_ff = dim_feedforward
+        self.dropout = dropout
+        self.max_seq_midi = max_sequence_midi
+        self.max_seq_video = max_sequence_video
+        self.max_seq_chord = max_sequence_chord
+        self.rpr = rpr
+        self.scene_embed = scene_embed
+        self.chord_embed = chord_embed
+        self.total_vf_dim = total_vf_dim
+
+        self.embedding = nn.Embedding(CHORD_SIZE, d_model)
+        self.embedding_root = nn.Embedding(CHORD_ROOT_SIZE, d_model)
+        self.embedding_attr = nn.Embedding(CHORD_ATTR_SIZE, d_model)
+        self.Linear_vis = nn.Linear(total_vf_dim, d_model)
+        self.Linear_chord = nn.Linear(d_model + 1, d_model)
+        self.positional_encoding = PositionalEncoding(d_model, dropout, max_sequence_chord)
+        self.positional_encoding_video = PositionalEncoding(d_model, dropout, max_sequence_video)
+        self.condition_linear = nn.Linear(1, d_model)
+        self.transformer = _TransformerParams(d_model, num_heads, n_layers, dim_feedforward, max_sequence_chord)
+        self.Wout_root = nn.Linear(d_model, CHORD_ROOT_SIZE)
+        self.Wout_attr = nn.Linear(d_model, CHORD_ATTR_SIZE)
+        self.Wout = nn.Linear(d_model, CHORD_SIZE)
+        self.softmax = nn.Softmax(dim=-1)
+
+        self._handle = None
+        self._weights_sig = None
+
+    # ------------------------------------------------------------------------------------------
+    # library handle / weight upload
+    # ------------------------------------------------------------------------------------------
+    def _device(self):
+        dev = self.Wout.weight.device
+        if dev.type != "cuda":
+            raise _lib.AmtError("VideoMusicTransformer runs on an MI355X only: move the module to a GPU "
+                                "(`.to('cuda')`); video2music_amd has no CPU fallback")
+        return dev
+
+    def _ensure_handle(self):
+        dev = self._device()
+        torch.cuda.set_device(dev)
+        if self._handle is None:
+            cfg = _lib.AmtConfig(self.nlayers, self.nhead, self.d_model, self.d_ff, self.max_seq_video,
+                                 self.max_seq_chord, self.total_vf_dim, MAX_DECODE_BATCH)
+            h = C.c_void_p()
+            _lib.call("amt_create", C.byref(cfg), C.byref(h))
+            self._handle = h
+            self._weights_sig = None
+        sig = tuple((k, v.data_ptr(), v._version) for k, v in self.state_dict().items())
+        if sig != self._weights_sig:
+            torch.cuda.synchronize(dev)
+            for name, t in self.state_dict().items():
+                t = t.detach().to(torch.float32).contiguous()
+                shape = (C.c_int64 * t.dim())(*t.shape)
+                _lib.call("amt_load_weight", self._handle, name.encode(), _lib.ptr(t), t.dim(), shape)
+            _lib.call("amt_finalize", self._handle)
+            self._weights_sig = sig
+        return self._handle
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None:
+            try:
+                _lib.call("amt_destroy", h)
+            except Exception:
+                pass
+
+    # ------------------------------------------------------------------------------------------
+    # feature plumbing
+    # ------------------------------------------------------------------------------------------
+    def _prep_features(self, sem, key, scene, motion, emotion, B=None):
+        dev = self._device()
+
+        def f(t):
+            return t.to(device=dev, dtype=torch.float32).contiguous()
+
+        sem, scene, emotion = f(sem), f(scene), f(emotion)
+        motion = f(motion)
+        if sem.dim() == 2:
+            sem = sem.unsqueeze(0)
+        B = sem.shape[0] if B is None else B
+        S = sem.shape[1]
+        if motion.dim() == 2:                       # scalar motion per frame (motion_type 0), :1012-1015
+            motion = motion.unsqueeze(-1).contiguous()
+        key = f(key).reshape(-1)
+        if key.numel() == 1:                        # feature_key.item() broadcast, :991-997
+            key = key.expand(B).contiguous()
+        assert key.numel() == B, f"feature_key has {key.numel()} entries for {B} clips"
+        assert scene.shape == (B, S) and motion.shape[:2] == (B, S) and emotion.shape[:2] == (B, S), "feature shapes disagree"
+        return sem, key, scene, motion, emotion, B, S
+
+    def _encode(self, h, sem, scene, motion, emotion, sl, memory_out=None):
+        B, S = sem[sl].shape[0], sem.shape[1]
+        _lib.call("amt_encode", h, B, S, _lib.ptr(sem[sl].contiguous()), sem.shape[2], _lib.ptr(scene[sl].contiguous()),
+                  _lib.ptr(motion[sl].contiguous()), motion.shape[2], _lib.ptr(emotion[sl].contiguous()), emotion.shape[2],
+                  _lib.ptr(memory_out), _lib.stream_ptr())
+
+    # ------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------
+    def forward(self, x, x_root, x_attr, feature_semantic_list, feature_key, feature_scene_offset,
+                feature_motion, feature_emotion, mask=True):
+        """Teacher-forced pass, reference ``forward`` (:978-1044).  Returns logits (B,L,159) fp32.
+
+        ``x`` is only used for its shape, like in the reference (:985-987 consume root/attr).
+        """
+        if mask is not True:
+            raise NotImplementedError("forward(mask=False) is not part of the hot path; every reference caller "
+                                      "uses the causal mask (utilities/run_model_vevo.py:84-91)")
+        h = self._ensure_handle()
+        dev = self._device()
+        B, L = x.shape[0], x.shape[1]
+        sem, key, scene, motion, emotion, Bf, S = self._prep_features(feature_semantic_list, feature_key,
+                                                                     feature_scene_offset, feature_motion, feature_emotion)
+        assert Bf == B, f"{B} chord sequences but {Bf} clips of video features"
+        roots = x_root.to(device=dev, dtype=torch.long).contiguous()
+        attrs = x_attr.to(device=dev, dtype=torch.long).contiguous()
+        logits = torch.empty(B, L, CHORD_SIZE, device=dev, dtype=torch.float32)
+        for b0 in range(0, B, MAX_DECODE_BATCH):
+            sl = slice(b0, min(B, b0 + MAX_DECODE_BATCH))
+            nb = sl.stop - sl.start
+            self._encode(h, sem, scene, motion, emotion, sl)
+            out = logits[sl]
+            _lib.call("amt_prefill", h, nb, L, _lib.ptr(roots[sl].contiguous()), _lib.ptr(attrs[sl].contiguous()),
+                      _lib.ptr(key[sl].contiguous()), _lib.ptr(out), None, -1, _lib.stream_ptr())
+        if IS_SEPERATED:
+            raise NotImplementedError("IS_SEPERATED heads are disabled in the reference (utilities/constants.py:11)")
+        return logits
+
+    def forward_debug(self, x_root, x_attr, feature_semantic_list, feature_key, feature_scene_offset,
+                      feature_motion, feature_emotion, layer_index=0):
+        """(logits, encoder memory (B,S,d), output of decoder layer ``layer_index`` (B,L,d)) for parity tests."""
+        h = self._ensure_handle()
+        dev = self._device()
+        sem, key, scene, motion, emotion, B, S = self._prep_features(feature_semantic_list, feature_key,
+                                                                    feature_scene_offset, feature_motion, feature_emotion)
+        assert B <= MAX_DECODE_BATCH
+        L = x_root.shape[1]
+        memory = torch.empty(B, S, self.d_model, device=dev)
+        layer = torch.empty(B, L, self.d_model, device=dev)
+        logits = torch.empty(B, L, CHORD_SIZE, device=dev)
+        self._encode(h, sem, scene, motion, emotion, slice(0, B), memory)
+        _lib.call("amt_prefill", h, B, L, _lib.ptr(x_root.to(dev).long().contiguous()), _lib.ptr(x_attr.to(dev).long().contiguous()),
+                  _lib.ptr(key), _lib.ptr(logits), _lib.ptr(layer), layer_index, _lib.stream_ptr())
+        return logits, memory, layer
+
+    # ------------------------------------------------------------------------------------------
+    # generate
+    # ------------------------------------------------------------------------------------------
+    def generate(self, feature_semantic_list=[], feature_key=None, feature_scene_offset=None, feature_motion=None,
+                 feature_emotion=None, primer=None, primer_root=None, primer_attr=None, target_seq_length=300,
+                 beam=0, beam_chance=1.0, max_conseq_N=0, max_conseq_chord=2, sampler="categorical"):
+        """Reference ``generate`` (:1046-1132) for one clip: returns a LongTensor (1, target_seq_length)."""
+        assert (not self.training), "Cannot generate while in training mode"
+        print("Generating sequence of max length:", target_seq_length)
+        return self.generate_batch(feature_semantic_list, feature_key, feature_scene_offset, feature_motion,
+                                   feature_emotion, primer, primer_root, primer_attr, target_seq_length, beam,
+                                   beam_chance, max_conseq_N, max_conseq_chord, sampler)[:1]
+
+    def generate_batch(self, feature_semantic_list, feature_key, feature_scene_offset, feature_motion, feature_emotion,
+                       primer, primer_root, primer_attr, target_seq_length=300, beam=0, beam_chance=1.0,
+                       max_conseq_N=0, max_conseq_chord=2, sampler="categorical", return_logits=False):
+        """Batched generate: features (B,S,·), primer (P,) shared or (B,P) per clip -> LongTensor (B,T).
+
+        beam=1 is the reference's deterministic top-1 branch (oracle G1; generated ids never feed
+        back, :1078-1084).  beam=0 is the sampling branch (:1085-1128) with
+        ``sampler="categorical"`` (random, torch RNG) or ``"argmax"`` (oracle G2).
+        """
+        assert (not self.training), "Cannot generate while in training mode"
+        if beam not in (0, 1):
+            raise NotImplementedError("beam > 1 is not implemented (generate.py:347-349 asserts it out as well)")
+        if beam == 1 and beam_chance < 1.0:
+            raise NotImplementedError("beam_chance < 1 mixes the two branches at random; not a parity target")
+        if sampler not in ("categorical", "argmax"):
+            raise ValueError(f"unknown sampler {sampler!r}")
+        h = self._ensure_handle()
+        dev = self._device()
+        sem, key, scene, motion, emotion, B, S = self._prep_features(feature_semantic_list, feature_key,
+                                                                    feature_scene_offset, feature_motion, feature_emotion)
+        T = int(target_seq_length)
+        prim = [torch.as_tensor(p).to(device=dev, dtype=torch.long).contiguous() for p in (primer, primer_root, primer_attr)]
+        per_clip = prim[0].dim() == 2
+        P = prim[0].shape[-1]
+        assert all(p.shape == prim[0].shape for p in prim), "primer / primer_root / primer_attr shapes differ"
+        assert (not per_clip) or prim[0].shape[0] == B
+        tokens = torch.empty(B, T, device=dev, dtype=torch.long)
+        logits = torch.zeros(T, B, CHORD_SIZE, device=dev) if return_logits else None
+        for b0 in range(0, B, MAX_DECODE_BATCH):
+            sl = slice(b0, min(B, b0 + MAX_DECODE_BATCH))
+            nb = sl.stop - sl.start
+            self._encode(h, sem, scene, motion, emotion, sl)
+            pr = [p[sl].contiguous() if per_clip else p for p in prim]
+            lg = torch.zeros(T, nb, CHORD_SIZE, device=dev) if return_logits else None
+            out = torch.empty(nb, T, device=dev, dtype=torch.long)
+            st = _lib.stream_ptr()
+            _lib.call("amt_generate_begin", h, nb, _lib.ptr(pr[0]), _lib.ptr(pr[1]), _lib.ptr(pr[2]), P, int(per_clip),
+                      _lib.ptr(key[sl].contiguous()), T, beam, int(max_conseq_N), int(max_conseq_chord), st)
+            if beam == 1 or sampler == "argmax":
+                _lib.call("amt_generate_run", h, -1, _lib.ptr(lg), st)
+            else:
+                probs = torch.empty(nb, CHORD_END, device=dev)
+                for cur in range(1, T):
+                    _lib.call("amt_generate_step_probs", h, _lib.ptr(probs), st)
+                    if cur >= P:       # Categorical(probs).sample(), :1104-1105
+                        chosen = torch.multinomial(probs, 1).reshape(nb).contiguous()
+                    else:              # still inside the primer: the commit keeps the given token
+                        chosen = torch.zeros(nb, device=dev, dtype=torch.long)
+                    _lib.call("amt_generate_commit", h, _lib.ptr(chosen), st)
+            _lib.call("amt_generate_end", h, _lib.ptr(out), st)
+            tokens[sl] = out
+            if return_logits:
+                logits[:, sl] = lg
+        return (tokens, logits) if return_logits else tokens
