@@ -88,6 +88,7 @@ struct amt_handle {
     struct GraphKey { int B, T, P, beam, mcN, mcC, S, nsteps; float* logits; };
     struct GraphEntry { GraphKey key; hipGraphExec_t exec; hipGraph_t graph; };
     std::vector<GraphEntry> graphs;
+    hipStream_t cap_stream = nullptr;    // capture-only stream (the caller's may be the legacy null stream)
 };
 
 namespace {
@@ -235,18 +236,22 @@ int32_t enqueue_decoder_step(amt_handle* h, hipStream_t s) {
     return 0;
 }
 
-int32_t get_graph(amt_handle* h, int nsteps, float* logits_out, hipStream_t s, hipGraphExec_t* out) {
+int32_t get_graph(amt_handle* h, int nsteps, float* logits_out, hipGraphExec_t* out) {
     amt_handle::GraphKey key{h->genB, h->genT, h->genP, h->beam, h->mcN, h->mcC, h->encS, nsteps, logits_out};
     for (auto& g : h->graphs)
         if (memcmp(&g.key, &key, sizeof(key)) == 0) { *out = g.exec; return 0; }
     hipGraph_t graph;
-    AMT_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    // capture on a private stream: nothing executes during capture, and torch's current stream is
+    // often the legacy null stream, which cannot be captured; the graph is launched on the caller's
+    if (!h->cap_stream) AMT_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+    hipStream_t cs = h->cap_stream;
+    AMT_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
     int32_t rc = 0;
     for (int i = 0; i < nsteps && !rc; ++i) {
-        rc = enqueue_decoder_step(h, s);
-        if (!rc) rc = amt_launch_sample(sample_params(h, logits_out, nullptr, 0), s);
+        rc = enqueue_decoder_step(h, cs);
+        if (!rc) rc = amt_launch_sample(sample_params(h, logits_out, nullptr, 0), cs);
     }
-    hipError_t e = hipStreamEndCapture(s, &graph);
+    hipError_t e = hipStreamEndCapture(cs, &graph);
     if (rc) { if (e == hipSuccess) (void)hipGraphDestroy(graph); return rc; }
     AMT_HIP(e);
     hipGraphExec_t exec;
@@ -285,6 +290,7 @@ extern "C" int32_t amt_destroy(amt_handle* h) {
     if (!h) return 0;
     (void)hipDeviceSynchronize();
     for (auto& g : h->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     for (void* p : h->owned) (void)hipFree(p);
     delete h;
     return 0;
@@ -582,7 +588,7 @@ extern "C" int32_t amt_generate_run(amt_handle* h, int32_t n_steps, float* logit
     while (left > 0) {
         const int ns = left >= STEPS_PER_GRAPH ? STEPS_PER_GRAPH : 1;
         hipGraphExec_t exec;
-        if ((rc = get_graph(h, ns, logits_out, s, &exec))) return rc;
+        if ((rc = get_graph(h, ns, logits_out, &exec))) return rc;
         AMT_HIP(hipGraphLaunch(exec, s));
         left -= ns;
     }

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, 
 
 // x viewed as [n0][seq][n2][hd]; cache flat [seq*cache_half*2] reinterpreted as [n0'][seq][hd/2][2]
 __global__ void rope_kernel(const float* __restrict__ x, const float* __restrict__ cache, float* __restrict__ y,
-                            int n0, int seq, int n2, int hd, long total_pairs) {
+                            int n0, int seq, int n2, int hd, long total_pairs, int bcast) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total_pairs) return;
     const int half = hd / 2;
@@ -109,7 +109,7 @@ __global__ void rope_kernel(const float* __restrict__ x, const float* __restrict
     long r = i / half;
     r /= n2;                                 // drop n2 (cache broadcasts over it)
     int s = (int)(r % seq);
-    int a = (int)(r / seq);
+    int a = bcast ? 0 : (int)(r / seq);     // a single cache slab broadcasts over the leading axis
     size_t ci = (((size_t)a * seq + s) * half + p) * 2;
     float c = cache[ci], sn = cache[ci + 1];
     float x0 = x[2 * i], x1 = x[2 * i + 1];
@@ -176,10 +176,13 @@ int32_t amt_launch_rmsnorm(const float* x, const float* w, float* y, int rows, i
 int32_t amt_launch_rope(const float* x, const float* cache, float* y, int n0, int seq, int n2, int hd,
                         int cache_half, hipStream_t stream) {
     AMT_CHECK_ARG(n0 > 0 && seq > 0 && n2 > 0 && hd > 0 && hd % 2 == 0, "rope: bad shape");
-    // the [n0'][seq][hd/2][2] reinterpretation of the [seq][cache_half][2] cache must cover n0 slabs
-    AMT_CHECK_ARG((long)cache_half * 2 >= (long)n0 * hd, "rope: cache has %d pairs per position, need %d", cache_half, n0 * hd / 2);
+    // the [n0'][seq][hd/2][2] reinterpretation of the [seq][cache_half][2] cache (rotate_operation.py:148-149)
+    // must either cover the n0 leading slabs or consist of exactly one slab, which then broadcasts
+    const int bcast = (cache_half * 2 == hd) ? 1 : 0;
+    AMT_CHECK_ARG(bcast || (long)cache_half * 2 >= (long)n0 * hd, "rope: cache has %d pairs per position, need %d (or exactly %d)",
+                  cache_half, n0 * hd / 2, hd / 2);
     long total = (long)n0 * seq * n2 * (hd / 2);
-    hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, cache, y, n0, seq, n2, hd, total);
+    hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, cache, y, n0, seq, n2, hd, total, bcast);
     AMT_LAUNCH_CHECK();
     return 0;
 }
