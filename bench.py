@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Headline benchmark: chord-tokens/s of batched autoregressive generate (BASELINE.json).
+
+One "step" = one pass of the hot path over one batch: video encode + feedback-greedy (G2) decode of
+B=32 clips per GPU to T=1024 tokens (+ the all-gather of ids when N>1), inputs resident in HBM.
+Workload = BASELINE.json configs[1]: 6+6 layers, d_model=512, H=8, dff=1024, max_sequence_chord=1024,
+300-frame synthetic video features (F=1287), random-init procedural weights.
+
+    python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torchrun, one rank per GPU)
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (attn_decode_kernel<64>, the
+K/V-streaming attention of the decode step): algorithmic fp32 K/V bytes / launch duration measured
+with HIP events on the launch stream in an instrumented eager replay of the same generate.
+`cpu_baseline` times the CPU oracle (port of the reference's no-KV-cache loop) on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from video2music_amd import dist as vdist                                   # noqa: E402
+from video2music_amd import synthetic                                        # noqa: E402
+from video2music_amd.model.video_music_transformer import VideoMusicTransformer   # noqa: E402
+from video2music_amd.utilities import constants as C                          # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+
+
+def make_model(cfg, device, seed=0):
+    m = VideoMusicTransformer(**cfg).eval()
+    shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=seed).items()}
+    m.load_state_dict(sd, strict=False)
+    return m.to(device), sd
+
+
+def cpu_baseline(cfg, sd, T, budget_s=25.0):
+    """Per-length cost of one step of the reference loop (full re-forward incl. encoder, no KV
+    cache, B=1: model/video_music_transformer.py:1069-1071) integrated over the T-1 steps of a clip."""
+    from oracle import amt_oracle as O
+    feats = synthetic.synthetic_features(1, seed=99)
+    f = {k: torch.from_numpy(v) for k, v in feats.items()}
+    lengths = [1, T // 8, T // 4, T // 2, (3 * T) // 4, T - 1]
+    rs = np.random.RandomState(0)
+    cost = []
+    t_start = time.time()
+    with torch.no_grad():
+        for L in lengths:
+            root = torch.from_numpy(rs.randint(1, 13, size=(1, L)))
+            attr = torch.from_numpy(rs.randint(1, 14, size=(1, L)))
+            reps, best = 0, float("inf")
+            while reps < 2 or (reps < 3 and time.time() - t_start < budget_s * 0.6):
+                t0 = time.perf_counter()
+                O.forward(sd, cfg["num_heads"], root, attr, f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"])
+                best = min(best, time.perf_counter() - t0)
+                reps += 1
+            cost.append(best)
+    per_clip = float(np.trapezoid(np.interp(np.arange(1, T), lengths, cost)))
+    return {"value": round((T - 1) / per_clip, 3), "unit": "chord-tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle forward (no KV cache, encoder re-run, B=1) timed at L={lengths} (best of 2-3), "
+                      f"integrated over the {T - 1} steps of one clip = {per_clip:.1f} s/clip; clips run sequentially",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--seq", type=int, default=1024, help="target_seq_length = max_sequence_chord")
+    ap.add_argument("--layers", type=int, default=6)
+    ap.add_argument("--d_model", type=int, default=512)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = vdist.init()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    B, T = args.batch, args.seq
+    heads = 8 if args.d_model >= 512 else 4
+    cfg = dict(n_layers=args.layers, num_heads=heads, d_model=args.d_model, dim_feedforward=2 * args.d_model,
+               max_sequence_chord=T, total_vf_dim=synthetic.total_vf_dim(1), rpr=True)
+    model, sd = make_model(cfg, device)
+    feats = synthetic.synthetic_features(B, seed=1234 + rank)
+    f = {k: torch.from_numpy(v).to(device) for k, v in feats.items()}
+    pr, prr, pra = (torch.tensor([v], device=device) for v in C.primer_from_name("C"))
+    P = 1
+
+    def step():
+        toks = model.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], pr, prr, pra,
+                                    target_seq_length=T, beam=0, sampler="argmax")
+        return vdist.all_gather_sequences(toks, world * B)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(device)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(te, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(te)
+    assert out.shape == (world * B, T)
+    tokens = world * B * (T - P) * args.steps
+    result = {
+        "metric": "chord_tokens_per_sec_generated", "value": round(tokens / elapsed, 1), "unit": "chord-tokens/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"AMT {args.layers}+{args.layers} layers d_model={args.d_model} H={heads} dff={2 * args.d_model} rpr, "
+                               f"seq={T}, batch={B} clips/GPU x 300-frame video features (F={cfg['total_vf_dim']}), "
+                               "feedback-greedy (G2) generate incl. video encode" + (" + all_gather of ids" if world > 1 else ""),
+                   "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}"},
+    }
+    if rank == 0 and world == 1 and not args.no_roofline:
+        with torch.no_grad():
+            _, st = model.generate_profile(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], pr, prr, pra,
+                                           target_seq_length=T)
+        empty_us = 1e3 * st["empty_event_pair"]["ms"] / st["empty_event_pair"]["launches"]
+
+        def avg_us(k):           # event-pair time minus the cost of an empty pair
+            return max(1e3 * st[k]["ms"] / st[k]["launches"] - empty_us, 1e-3)
+
+        def gbs(k):
+            return st[k]["bytes"] / st[k]["launches"] / (avg_us(k) * 1e-6) / 1e9
+
+        names = {"self_attn_decode": "attn_decode_kernel<64, true> (relative-position self-attention)",
+                 "cross_attn_decode": "attn_decode_kernel<64, false> (cross-attention over video K/V)"}
+        dom = max(names, key=lambda k: avg_us(k) * st[k]["launches"])
+        other = [k for k in names if k != dom][0]
+        result["roofline"] = {
+            "bound": "hbm", "kernel": names[dom], "achieved": round(gbs(dom), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs(dom) / HBM_PEAK_GBS, 4), "traffic": None,
+            "launches": st[dom]["launches"], "avg_launch_us": round(avg_us(dom), 3),
+            "algorithmic_bytes_per_launch": round(st[dom]["bytes"] / st[dom]["launches"]),
+            "measured": "HIP event pair on the launch stream around every launch of an eager replay of one full generate, "
+                        f"minus the empty-pair cost ({empty_us:.2f} us)",
+            "second_kernel": {"kernel": names[other], "achieved": round(gbs(other), 1), "avg_launch_us": round(avg_us(other), 3),
+                              "algorithmic_bytes_per_launch": round(st[other]["bytes"] / st[other]["launches"])},
+            "other_kernels_avg_us": {k: round(avg_us(k), 3) for k in ("decode_gemm", "sample")},
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(cfg, sd, T)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

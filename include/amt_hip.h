@@ -87,6 +87,14 @@ int32_t amt_generate_begin(amt_handle* h, int32_t B, const int64_t* primer, cons
  * beam=0, G1 for beam=1).  logits_out (optional) is (T,B,159): row t = logits computed from input
  * position t.  n_steps < 0 runs to the end (T-1 steps in total). */
 int32_t amt_generate_run(amt_handle* h, int32_t n_steps, float* logits_out, void* stream);
+/* Same steps as amt_generate_run, issued eagerly with a HIP event pair recorded on `stream` around
+ * every kernel launch (synchronises once per step).  Accumulates, per kernel class
+ * {0: self-attention decode, 1: cross-attention decode, 2: skinny GEMMs, 3: sampling head,
+ * 4: an EMPTY event pair per step = the overhead of the two records, to be subtracted}, the
+ * summed pair durations (ms) and counts (arrays of 5), and for classes 0/1 the algorithmic K/V bytes
+ * (fp32 K and V rows of the keys each launch must read).  Used by bench.py's roofline leg. */
+int32_t amt_generate_profile(amt_handle* h, int32_t n_steps, double* ms_by_class, int64_t* launches_by_class,
+                             int64_t* attn_bytes_by_class, void* stream);
 /* One decode step that stops before the decision: writes the decision distribution
  * softmax(logits)[:157] with the suppressions applied, (B,157), for a host-side sampler
  * (torch.multinomial = the reference's Categorical.sample), then amt_generate_commit feeds the

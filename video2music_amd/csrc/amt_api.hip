@@ -3,6 +3,7 @@
 // See include/amt_hip.h for the contract and the reference code each entry point replaces.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -178,8 +179,25 @@ SampleParams sample_params(amt_handle* h, float* logits_out, float* probs_out, i
     return p;
 }
 
+// Optional per-launch timing of an eagerly issued step (bench.py's roofline leg): HIP events are
+// recorded on the launch stream right before / after each kernel, classes: 0 = relative-position
+// self-attention, 1 = cross-attention, 2 = skinny GEMMs, 3 = sampling head.
+struct StepProf {
+    std::vector<hipEvent_t> ev;
+    std::vector<int> cls;
+    size_t used = 0;
+    hipStream_t s = nullptr;
+    void begin() {
+        if (used + 2 > ev.size()) { ev.resize(used + 2, nullptr); (void)hipEventCreate(&ev[used]); (void)hipEventCreate(&ev[used + 1]); }
+        (void)hipEventRecord(ev[used], s);
+    }
+    void end(int c) { (void)hipEventRecord(ev[used + 1], s); cls.push_back(c); used += 2; }
+};
+#define PROF_BEGIN() do { if (prof) prof->begin(); } while (0)
+#define PROF_END(c) do { if (prof) prof->end(c); } while (0)
+
 // the kernels of one decode step up to (not including) the sampling head
-int32_t enqueue_decoder_step(amt_handle* h, hipStream_t s) {
+int32_t enqueue_decoder_step(amt_handle* h, hipStream_t s, StepProf* prof = nullptr) {
     const int B = h->genB, d = h->d, dff = h->dff, H = h->H, hd = h->hd;
     const float qscale = 1.0f / sqrtf((float)hd);
     int32_t rc;
@@ -196,42 +214,58 @@ int32_t enqueue_decoder_step(amt_handle* h, hipStream_t s) {
         if (l > 0) { g.ln_w = h->dec[l - 1].n3w; g.ln_b = h->dec[l - 1].n3b; g.xn = h->xa; }
         g.mode = 1; g.y = h->qb; g.ldy = d; g.scale = qscale; g.scale_cols = d;
         g.kcache = Kc; g.vcache = Vc; g.H = H; g.hd = hd; g.cap = h->Tcap; g.pos = h->pos; g.d = d;
+        PROF_BEGIN();
         if ((rc = amt_launch_decode_gemm(g, s))) return rc;
+        PROF_END(2);
         const float* r0 = l == 0 ? h->x_in : h->xa;
         // K2: relative-position self-attention over the cache
         AttnDecodeParams a{};
         a.q = h->qb; a.k = Kc; a.v = Vc; a.o = h->ob; a.B = B; a.H = H; a.hd = hd; a.cap = h->Tcap;
         a.pos = h->pos; a.Er = L.Er; a.er_len = h->Tcap;
+        PROF_BEGIN();
         if ((rc = amt_launch_attn_decode(a, s))) return rc;
+        PROF_END(0);
         // K3: out-proj + residual
         DecodeGemmParams o{};
         o.B = B; o.eps = LN_EPS; o.scale = 1.f; o.x = h->ob; o.ldx = d; o.Wp = L.p_sao; o.bias = L.sa_ob; o.N = d; o.K = d;
         o.resid = r0; o.ldr = d; o.y = h->u1; o.ldy = d;
+        PROF_BEGIN();
         if ((rc = amt_launch_decode_gemm(o, s))) return rc;
+        PROF_END(2);
         // K4: LN1 + cross-attention query projection
         DecodeGemmParams c{};
         c.B = B; c.eps = LN_EPS; c.x = h->u1; c.ldx = d; c.Wp = L.p_caq; c.bias = L.ca_b; c.N = d; c.K = d;
         c.ln_w = L.n1w; c.ln_b = L.n1b; c.xn = h->xb; c.scale = qscale; c.scale_cols = d; c.y = h->qb; c.ldy = d;
+        PROF_BEGIN();
         if ((rc = amt_launch_decode_gemm(c, s))) return rc;
+        PROF_END(2);
         // K5: cross-attention over the clip's video keys
         AttnDecodeParams x{};
         x.q = h->qb; x.k = Kx; x.v = Vx; x.o = h->ob; x.B = B; x.H = H; x.hd = hd; x.cap = h->Scap; x.n_keys = h->encS;
+        PROF_BEGIN();
         if ((rc = amt_launch_attn_decode(x, s))) return rc;
+        PROF_END(1);
         // K6: out-proj + residual
         DecodeGemmParams o2{};
         o2.B = B; o2.eps = LN_EPS; o2.scale = 1.f; o2.x = h->ob; o2.ldx = d; o2.Wp = L.p_cao; o2.bias = L.ca_ob; o2.N = d; o2.K = d;
         o2.resid = h->xb; o2.ldr = d; o2.y = h->u2; o2.ldy = d;
+        PROF_BEGIN();
         if ((rc = amt_launch_decode_gemm(o2, s))) return rc;
+        PROF_END(2);
         // K7: LN2 + FFN up + ReLU
         DecodeGemmParams f1{};
         f1.B = B; f1.eps = LN_EPS; f1.scale = 1.f; f1.x = h->u2; f1.ldx = d; f1.Wp = L.p_l1; f1.bias = L.l1b; f1.N = dff; f1.K = d;
         f1.ln_w = L.n2w; f1.ln_b = L.n2b; f1.xn = h->xc; f1.relu = 1; f1.y = h->hb; f1.ldy = dff;
+        PROF_BEGIN();
         if ((rc = amt_launch_decode_gemm(f1, s))) return rc;
+        PROF_END(2);
         // K8: FFN down + residual
         DecodeGemmParams f2{};
         f2.B = B; f2.eps = LN_EPS; f2.scale = 1.f; f2.x = h->hb; f2.ldx = dff; f2.Wp = L.p_l2; f2.bias = L.l2b; f2.N = d; f2.K = dff;
         f2.resid = h->xc; f2.ldr = d; f2.y = h->u3; f2.ldy = d;
+        PROF_BEGIN();
         if ((rc = amt_launch_decode_gemm(f2, s))) return rc;
+        PROF_END(2);
     }
     return 0;
 }
@@ -596,6 +630,46 @@ extern "C" int32_t amt_generate_run(amt_handle* h, int32_t n_steps, float* logit
     return 0;
 }
 
+extern "C" int32_t amt_generate_profile(amt_handle* h, int32_t n_steps, double* ms_by_class, int64_t* launches_by_class,
+                                        int64_t* attn_bytes_by_class, void* stream) {
+    AMT_CHECK_ARG(h && h->gen_active && ms_by_class && launches_by_class && attn_bytes_by_class, "amt_generate_profile: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int remaining = h->genT - 1 - h->steps_done;
+    if (n_steps < 0 || n_steps > remaining) n_steps = remaining;
+    StepProf prof;
+    prof.s = s;
+    for (int c = 0; c < 5; ++c) { ms_by_class[c] = 0.0; launches_by_class[c] = 0; }
+    attn_bytes_by_class[0] = attn_bytes_by_class[1] = 0;
+    int32_t rc = 0;
+    for (int i = 0; i < n_steps && !rc; ++i) {
+        prof.used = 0; prof.cls.clear();
+        rc = enqueue_decoder_step(h, s, &prof);
+        if (rc) break;
+        prof.begin();
+        rc = amt_launch_sample(sample_params(h, nullptr, nullptr, 0), s);
+        prof.end(3);
+        if (rc) break;
+        prof.begin();            // class 4: an empty pair = the cost of the event records themselves
+        prof.end(4);
+        hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { amt_set_error("amt_generate_profile: %s", hipGetErrorString(e)); rc = (int32_t)e; break; }
+        for (size_t k = 0; k < prof.cls.size(); ++k) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, prof.ev[2 * k], prof.ev[2 * k + 1]);
+            ms_by_class[prof.cls[k]] += ms;
+            launches_by_class[prof.cls[k]] += 1;
+        }
+        // algorithmic K/V bytes of this step's attention launches: keys 0..t for self, S for cross
+        const int64_t row = (int64_t)h->d * 4 * 2 * h->genB;
+        attn_bytes_by_class[0] += (int64_t)h->nl * (h->steps_done + i + 1) * row;
+        attn_bytes_by_class[1] += (int64_t)h->nl * h->encS * row;
+    }
+    for (auto e : prof.ev) if (e) (void)hipEventDestroy(e);
+    if (rc) return rc;
+    h->steps_done += n_steps;
+    return 0;
+}
+
 extern "C" int32_t amt_generate_step_probs(amt_handle* h, float* probs_out, void* stream) {
     AMT_CHECK_ARG(h && h->gen_active && probs_out, "amt_generate_step_probs: no generation in progress");
     AMT_CHECK_ARG(h->steps_done < h->genT - 1, "amt_generate_step_probs: sequence is complete");
@@ -718,11 +792,16 @@ extern "C" int32_t amt_decode_linear_fwd(const float* x, const float* w, const f
                                          int32_t B, int32_t N, int32_t K, int32_t relu, float eps, void* stream) {
     AMT_CHECK_ARG(x && w && y && w_packed_scratch, "amt_decode_linear_fwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    int32_t rc = amt_launch_pack_weight(w, w_packed_scratch, N, K, s);
-    if (rc) return rc;
+    int dbg = 0;
+    if (const char* e = getenv("AMT_DBG")) dbg = atoi(e);          // micro-benchmark ablations only
+    if (!(dbg & 16)) {                                             // 16: scratch already holds the packed weight
+        int32_t rc = amt_launch_pack_weight(w, w_packed_scratch, N, K, s);
+        if (rc) return rc;
+    }
     DecodeGemmParams g{};
     g.x = x; g.ldx = K; g.Wp = w_packed_scratch; g.bias = bias; g.B = B; g.N = N; g.K = K;
     g.ln_w = ln_w; g.ln_b = ln_b; g.xn = xn_out; g.eps = eps; g.resid = resid; g.ldr = N; g.relu = relu;
     g.scale = 1.f; g.y = y; g.ldy = N;
+    g.dbg = dbg & 15;
     return amt_launch_decode_gemm(g, s);
 }

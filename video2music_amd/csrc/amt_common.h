@@ -34,22 +34,45 @@ void amt_set_error(const char* fmt, ...);
         }                                                                              \
     } while (0)
 
-// ---- wavefront reductions (64 lanes) ----
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- wavefront reductions (64 lanes) on the DPP cross-lane path ----
+// __shfl_xor lowers to ds_bpermute_b32 (an LDS round trip per step); the row-local DPP modifiers
+// below are plain VALU operands.  After quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror and
+// row_mirror every lane of a 16-lane row holds its row's total; rows are combined via readlane.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ float row_sum16(float v) {
+    v += dpp_mov<DPP_XOR1>(v);
+    v += dpp_mov<DPP_XOR2>(v);
+    v += dpp_mov<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_mov<DPP_ROW_MIRROR>(v);
     return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row_sum16(v);
+    return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_mov<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_mov<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_mov<DPP_ROW_MIRROR>(v));
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
 }
-// sum over the aligned group of G consecutive lanes (G power of two <= 64)
+// sum over the aligned group of G consecutive lanes (G power of two <= 64); every lane gets the total
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (G >= 2) v += dpp_mov<DPP_XOR1>(v);
+    if (G >= 4) v += dpp_mov<DPP_XOR2>(v);
+    if (G >= 8) v += dpp_mov<DPP_ROW_HALF_MIRROR>(v);
+    if (G >= 16) v += dpp_mov<DPP_ROW_MIRROR>(v);
+    if (G >= 32) v += __shfl_xor(v, 16, 64);
+    if (G >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
 

@@ -1,6 +1,6 @@
 // Single-query attention for the autoregressive decode step (HBM-bound K/V streaming).
 //
-// One 256-thread workgroup per (clip, head).  The head's K and V rows ([cap][hd] fp32, contiguous)
+// One 512-thread workgroup per (clip, head).  The head's K and V rows ([cap][hd] fp32, contiguous)
 // are streamed straight to registers with 16-byte lanes: hd/4 lanes cover one key row, so one
 // wave-instruction fetches 64/(hd/4) whole rows = 1 KiB fully coalesced.  Each lane group keeps an
 // online-softmax state (m, l, o[4]) for the keys it has seen; groups and waves are merged once at
@@ -16,13 +16,56 @@
 
 namespace {
 
+constexpr int NW = 8;            // waves per workgroup
+constexpr int UNROLL = 4;        // key groups per wave and batch
+
 template <int HD>
-__global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
+struct Batch {                   // one register-resident batch of UNROLL key groups
+    float4 k[UNROLL], v[UNROLL], e[UNROLL];
+};
+
+template <int HD, bool RPR>
+__device__ __forceinline__ void load_batch(Batch<HD>& bt, const float* kb, const float* vb, const float* eb,
+                                           int j0, int sub, int n_keys) {
+    constexpr int KPW = 64 / (HD / 4);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        const int j = j0 + u * NW * KPW + sub;
+        const int jj = j < n_keys ? j : 0;
+        bt.k[u] = ld4(kb + (size_t)jj * HD);
+        bt.v[u] = ld4(vb + (size_t)jj * HD);
+        if (RPR) bt.e[u] = ld4(eb + (size_t)jj * HD);
+    }
+}
+
+template <int HD, bool RPR>
+__device__ __forceinline__ void consume_batch(const Batch<HD>& bt, const float4 q4, int j0, int sub, int n_keys,
+                                              float& m, float& l, float4& o) {
+    constexpr int LPK = HD / 4, KPW = 64 / LPK;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        float4 k4 = bt.k[u];
+        if (RPR) { k4.x += bt.e[u].x; k4.y += bt.e[u].y; k4.z += bt.e[u].z; k4.w += bt.e[u].w; }
+        float s = q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
+        s = group_sum<LPK>(s);
+        if (j0 + u * NW * KPW + sub < n_keys) {
+            const float mn = fmaxf(m, s);
+            const float alpha = __expf(m - mn), pj = __expf(s - mn);
+            l = l * alpha + pj;
+            o.x = o.x * alpha + pj * bt.v[u].x; o.y = o.y * alpha + pj * bt.v[u].y;
+            o.z = o.z * alpha + pj * bt.v[u].z; o.w = o.w * alpha + pj * bt.v[u].w;
+            m = mn;
+        }
+    }
+}
+
+template <int HD, bool RPR>
+__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnDecodeParams p) {
     constexpr int LPK = HD / 4;          // lanes per key row
     constexpr int KPW = 64 / LPK;        // keys per wave-instruction
-    constexpr int UNROLL = 4;
-    __shared__ float sm_m[4], sm_l[4];
-    __shared__ __attribute__((aligned(16))) float sm_o[4][HD];
+    constexpr int STRIDE = NW * KPW * UNROLL;     // keys per workgroup batch
+    __shared__ float sm_m[NW], sm_l[NW];
+    __shared__ __attribute__((aligned(16))) float sm_o[NW][HD];
 
     const int h = blockIdx.x, b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -30,42 +73,25 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
     const int t = p.pos ? *p.pos : (p.n_keys - 1);
     const int n_keys = t + 1;
 
-    const float4 q4 = ld4(p.q + ((size_t)b * p.H + h) * HD + c * 4);
     const float* kb = p.k + ((size_t)b * p.H + h) * p.cap * HD + c * 4;
     const float* vb = p.v + ((size_t)b * p.H + h) * p.cap * HD + c * 4;
-    const float* eb = p.Er ? p.Er + (size_t)(p.er_len - 1 - t) * HD + c * 4 : nullptr;   // row of key 0
+    const float* eb = RPR ? p.Er + (size_t)(p.er_len - 1 - t) * HD + c * 4 : nullptr;   // Er row of key 0
 
+    // wave w takes key groups w, w+NW, ...; two batches are kept in flight (load i+1 before using i)
+    Batch<HD> b0, b1;
+    int j0 = wave * KPW;
+    load_batch<HD, RPR>(b0, kb, vb, eb, j0, sub, n_keys);
+    const float4 q4 = ld4(p.q + ((size_t)b * p.H + h) * HD + c * 4);
     float m = -INFINITY, l = 0.f;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    // wave w takes key groups w, w+4, ...; each iteration covers UNROLL groups of KPW keys
-    for (int j0 = wave * KPW; j0 < n_keys; j0 += 4 * KPW * UNROLL) {
-        float4 kk[UNROLL], vv[UNROLL], ee[UNROLL];
-        bool ok[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int j = j0 + u * 4 * KPW + sub;
-            ok[u] = j < n_keys;
-            const int jj = ok[u] ? j : 0;
-            kk[u] = ld4(kb + (size_t)jj * HD);
-            vv[u] = ld4(vb + (size_t)jj * HD);
-            if (eb) ee[u] = ld4(eb + (size_t)jj * HD);
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            float4 k4 = kk[u];
-            if (eb) { k4.x += ee[u].x; k4.y += ee[u].y; k4.z += ee[u].z; k4.w += ee[u].w; }
-            float s = q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
-            s = group_sum<LPK>(s);
-            if (ok[u]) {
-                const float mn = fmaxf(m, s);
-                const float alpha = __expf(m - mn), pj = __expf(s - mn);
-                l = l * alpha + pj;
-                o.x = o.x * alpha + pj * vv[u].x; o.y = o.y * alpha + pj * vv[u].y;
-                o.z = o.z * alpha + pj * vv[u].z; o.w = o.w * alpha + pj * vv[u].w;
-                m = mn;
-            }
-        }
+    while (j0 < n_keys) {
+        if (j0 + STRIDE < n_keys) load_batch<HD, RPR>(b1, kb, vb, eb, j0 + STRIDE, sub, n_keys);
+        consume_batch<HD, RPR>(b0, q4, j0, sub, n_keys, m, l, o);
+        j0 += STRIDE;
+        if (j0 >= n_keys) break;
+        if (j0 + STRIDE < n_keys) load_batch<HD, RPR>(b0, kb, vb, eb, j0 + STRIDE, sub, n_keys);
+        consume_batch<HD, RPR>(b1, q4, j0, sub, n_keys, m, l, o);
+        j0 += STRIDE;
     }
 
     // merge the KPW lane groups of the wave (lanes with equal c)
@@ -89,11 +115,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
     }
     __syncthreads();
     if (wave == 0 && sub == 0) {
-        float mn = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
+        float mn = sm_m[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) mn = fmaxf(mn, sm_m[w]);
         float lt = 0.f;
         float4 ot = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < NW; ++w) {
             const float a = (sm_m[w] == -INFINITY) ? 0.f : __expf(sm_m[w] - mn);
             const float4 ow = ld4(&sm_o[w][c * 4]);
             lt += sm_l[w] * a;
@@ -105,18 +133,24 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
     }
 }
 
+template <int HD>
+void launch_decode(const AttnDecodeParams& p, hipStream_t stream) {
+    dim3 grid(p.H, p.B);
+    if (p.Er) hipLaunchKernelGGL((attn_decode_kernel<HD, true>), grid, dim3(NW * 64), 0, stream, p);
+    else hipLaunchKernelGGL((attn_decode_kernel<HD, false>), grid, dim3(NW * 64), 0, stream, p);
+}
+
 }  // namespace
 
 int32_t amt_launch_attn_decode(const AttnDecodeParams& p, hipStream_t stream) {
     AMT_CHECK_ARG(p.B > 0 && p.H > 0 && p.cap > 0, "attn_decode: bad shape B=%d H=%d cap=%d", p.B, p.H, p.cap);
     AMT_CHECK_ARG(p.pos != nullptr || (p.n_keys > 0 && p.n_keys <= p.cap), "attn_decode: n_keys=%d outside (0,%d]", p.n_keys, p.cap);
     AMT_CHECK_ARG(p.Er == nullptr || p.er_len >= p.cap, "attn_decode: er_len=%d smaller than the key capacity %d", p.er_len, p.cap);
-    dim3 grid(p.H, p.B);
     switch (p.hd) {
-        case 16: hipLaunchKernelGGL(attn_decode_kernel<16>, grid, dim3(256), 0, stream, p); break;
-        case 32: hipLaunchKernelGGL(attn_decode_kernel<32>, grid, dim3(256), 0, stream, p); break;
-        case 64: hipLaunchKernelGGL(attn_decode_kernel<64>, grid, dim3(256), 0, stream, p); break;
-        case 128: hipLaunchKernelGGL(attn_decode_kernel<128>, grid, dim3(256), 0, stream, p); break;
+        case 16: launch_decode<16>(p, stream); break;
+        case 32: launch_decode<32>(p, stream); break;
+        case 64: launch_decode<64>(p, stream); break;
+        case 128: launch_decode<128>(p, stream); break;
         default: AMT_CHECK_ARG(false, "attn_decode: head_dim %d not in {16,32,64,128}", p.hd);
     }
     AMT_LAUNCH_CHECK();

@@ -91,6 +91,7 @@ struct DecodeGemmParams {
     float* y; int ldy;
     // mode 1
     float* kcache; float* vcache; int H, hd, cap; const int* pos; int d;
+    int dbg;                    // micro-benchmark ablation mask (0 in production): 1 no weight loads, 2 no x loads, 4 no LN, 8 no MFMA, 16 no LDS staging, 32 no epilogue
 };
 int32_t amt_launch_decode_gemm(const DecodeGemmParams& p, hipStream_t stream);
 

@@ -1,6 +1,6 @@
 // Output head of one decode step: final LayerNorms -> Wout -> softmax -> decision -> feedback.
 //
-// One 256-thread workgroup per clip.  Restates, on device and without host round trips, the body
+// One 1024-thread workgroup per clip.  Restates, on device and without host round trips, the body
 // of the reference's generate loop (model/video_music_transformer.py:1070-1131):
 //   y = softmax(logits)[:157]                      (END/PAD dropped, not renormalised, :1070-1071)
 //   beam==1 : tok = top-1(y); root/attr sequences are left at PAD                     (:1078-1084)
@@ -19,6 +19,7 @@ namespace {
 
 constexpr int V = 159, VP = 157;       // CHORD_SIZE, CHORD_END
 constexpr int ROOT_PAD = 14, ATTR_PAD = 15;
+constexpr int NWS = 16;                 // waves of the sampling workgroup
 
 __device__ __forceinline__ void write_next_input(const SampleParams& p, int b, int cur, int root, int attr) {
     const float kv = p.key[b];
@@ -46,7 +47,8 @@ __device__ __forceinline__ void advance_pos(const SampleParams& p, int t) {
     }
 }
 
-__global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
+template <int KCH>       // float4 chunks per lane covering d (d <= KCH*256)
+__global__ __launch_bounds__(NWS * 64) void sample_kernel(SampleParams p) {
     __shared__ __attribute__((aligned(16))) float ys[1024];
     __shared__ float logit[V + 1];
     __shared__ int s_tok;
@@ -56,9 +58,10 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
 
     // ---- LayerNorm(s) of the row, by wave 0 (d <= 1024: up to 4 float4 per lane) ----
     if (wave == 0) {
-        float4 v[4];
+        const float inv_d = 1.0f / (float)d;
+        float4 v[KCH];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < KCH; ++c) {
             const int i = (c * 64 + lane) * 4;
             v[c] = (i < d) ? ld4(p.u + (size_t)b * p.ldu + i) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -69,20 +72,20 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
             if (!gw) continue;
             float s = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) s += v[c].x + v[c].y + v[c].z + v[c].w;
-            const float mean = wave_sum(s) / d;
+            for (int c = 0; c < KCH; ++c) s += v[c].x + v[c].y + v[c].z + v[c].w;
+            const float mean = wave_sum(s) * inv_d;
             float q = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < KCH; ++c) {
                 const int i = (c * 64 + lane) * 4;
                 if (i < d) {
                     const float dx = v[c].x - mean, dy = v[c].y - mean, dz = v[c].z - mean, dw = v[c].w - mean;
                     q += dx * dx + dy * dy + dz * dz + dw * dw;
                 }
             }
-            const float rstd = 1.0f / sqrtf(wave_sum(q) / d + p.eps);
+            const float rstd = rsqrtf(wave_sum(q) * inv_d + p.eps);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < KCH; ++c) {
                 const int i = (c * 64 + lane) * 4;
                 if (i < d) {
                     const float4 g = ld4(gw + i), h = ld4(gb + i);
@@ -92,26 +95,49 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
             }
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < KCH; ++c) {
             const int i = (c * 64 + lane) * 4;
             if (i < d) st4(&ys[i], v[c]);
         }
     }
     __syncthreads();
 
-    // ---- logits = y . Wout^T + b : wave w takes rows w, w+4, ... ----
-    for (int n = wave; n < V; n += 4) {
-        float s = 0.f;
-        for (int i = lane * 4; i < d; i += 256) {
-            const float4 w = ld4(p.Wout + (size_t)n * d + i), y = ld4(&ys[i]);
-            s += w.x * y.x + w.y * y.y + w.z * y.z + w.w * y.w;
+    // ---- logits = y . Wout^T + b : wave w takes rows w, w+8, ...; RB rows are in flight at once so
+    //      the L2 round trips of the weight rows overlap (d <= 1024: up to 4 float4 per lane and row) ----
+    {
+        constexpr int RB = 5;
+        float4 yv[KCH];
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            const int i = (c * 64 + lane) * 4;
+            yv[c] = (i < d) ? ld4(&ys[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        s = wave_sum(s);
-        if (lane == 0) logit[n] = s + p.bout[n];
+        for (int n0 = wave; n0 < V; n0 += NWS * RB) {
+            float4 wv[RB][KCH];
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const int n = n0 + j * NWS;
+#pragma unroll
+                for (int c = 0; c < KCH; ++c) {
+                    const int i = (c * 64 + lane) * 4;
+                    wv[j][c] = (n < V && i < d) ? ld4(p.Wout + (size_t)n * d + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const int n = n0 + j * NWS;
+                float sdot = 0.f;
+#pragma unroll
+                for (int c = 0; c < KCH; ++c)
+                    sdot += wv[j][c].x * yv[c].x + wv[j][c].y * yv[c].y + wv[j][c].z * yv[c].z + wv[j][c].w * yv[c].w;
+                sdot = wave_sum(sdot);
+                if (lane == 0 && n < V) logit[n] = sdot + p.bout[n];
+            }
+        }
     }
     __syncthreads();
     if (p.logits_out)
-        for (int n = tid; n < V; n += 256) p.logits_out[((size_t)t * p.B + b) * V + n] = logit[n];
+        for (int n = tid; n < V; n += NWS * 64) p.logits_out[((size_t)t * p.B + b) * V + n] = logit[n];
 
     // ---- decision, by wave 0 ----
     if (wave == 0) {
@@ -229,7 +255,12 @@ __global__ __launch_bounds__(256) void embed_step_kernel(SampleParams p, int adv
 
 int32_t amt_launch_sample(const SampleParams& p, hipStream_t stream) {
     AMT_CHECK_ARG(p.B > 0 && p.d % 4 == 0 && p.d <= 1024, "sample: bad shape B=%d d=%d", p.B, p.d);
-    hipLaunchKernelGGL(sample_kernel, dim3(p.B), dim3(256), 0, stream, p);
+    switch ((p.d + 255) / 256) {
+        case 1: hipLaunchKernelGGL(sample_kernel<1>, dim3(p.B), dim3(NWS * 64), 0, stream, p); break;
+        case 2: hipLaunchKernelGGL(sample_kernel<2>, dim3(p.B), dim3(NWS * 64), 0, stream, p); break;
+        case 3: hipLaunchKernelGGL(sample_kernel<3>, dim3(p.B), dim3(NWS * 64), 0, stream, p); break;
+        default: hipLaunchKernelGGL(sample_kernel<4>, dim3(p.B), dim3(NWS * 64), 0, stream, p); break;
+    }
     AMT_LAUNCH_CHECK();
     return 0;
 }

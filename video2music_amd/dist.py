@@ -1,0 +1,61 @@
+"""Data-parallel sharding of video clips over the GPUs of one node (one process per GPU).
+
+The reference has no multi-device concept (``utilities/device.py:8-9`` hard-codes ``cuda:0``).
+Clips are independent units: each rank encodes and decodes its own shard with replicated weights
+and the only exchange is ONE ``all_gather`` of the generated ``(B_local, T)`` int64 id matrices at
+the end (256 KiB per rank at B_local=32, T=1024 — latency-bound).
+``torch.distributed`` backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend=None):
+    """Initialises the default process group from the torchrun environment (no-op for world size 1)."""
+    rank, world, local = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    return rank, world, local
+
+
+def shard_bounds(n_clips, rank, world):
+    """Contiguous shard [lo, hi) of ``n_clips`` for ``rank``; sizes differ by at most one."""
+    base, rem = divmod(n_clips, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_gather_sequences(tokens, n_clips=None):
+    """Gathers the per-rank ``(B_local, T)`` id matrices into the global ``(n_clips, T)`` matrix on
+    every rank, in rank order (= clip order under ``shard_bounds``).  Ragged shards are padded to
+    the largest shard for the collective and trimmed afterwards."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return tokens
+    world = dist.get_world_size()
+    sizes = [torch.zeros(1, dtype=torch.long, device=tokens.device) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([tokens.shape[0]], dtype=torch.long, device=tokens.device))
+    sizes = [int(s) for s in sizes]
+    mx = max(sizes)
+    pad = tokens
+    if tokens.shape[0] < mx:
+        pad = torch.cat([tokens, tokens.new_zeros(mx - tokens.shape[0], tokens.shape[1])])
+    out = torch.empty(world * mx, tokens.shape[1], dtype=tokens.dtype, device=tokens.device)
+    dist.all_gather_into_tensor(out, pad.contiguous()) if hasattr(dist, "all_gather_into_tensor") and tokens.is_cuda \
+        else dist.all_gather(list(out.view(world, mx, -1).unbind(0)), pad.contiguous())
+    parts = [out.view(world, mx, -1)[r, :sizes[r]] for r in range(world)]
+    res = torch.cat(parts)
+    assert n_clips is None or res.shape[0] == n_clips
+    return res

@@ -280,6 +280,35 @@ class VideoMusicTransformer(nn.Module):
                                    feature_emotion, primer, primer_root, primer_attr, target_seq_length, beam,
                                    beam_chance, max_conseq_N, max_conseq_chord, sampler)[:1]
 
+    def generate_profile(self, feature_semantic_list, feature_key, feature_scene_offset, feature_motion, feature_emotion,
+                         primer, primer_root, primer_attr, target_seq_length=300, max_conseq_N=0, max_conseq_chord=2):
+        """One feedback-greedy generate (<= 32 clips) issued eagerly with HIP events around every
+        decode kernel launch (``amt_generate_profile``).  Returns ``(tokens, stats)`` where stats maps
+        kernel class -> {"ms", "launches", "bytes"}; ``bytes`` = algorithmic fp32 K/V bytes."""
+        assert (not self.training), "Cannot generate while in training mode"
+        h = self._ensure_handle()
+        dev = self._device()
+        sem, key, scene, motion, emotion, B, S = self._prep_features(feature_semantic_list, feature_key,
+                                                                    feature_scene_offset, feature_motion, feature_emotion)
+        assert B <= MAX_DECODE_BATCH
+        T = int(target_seq_length)
+        prim = [torch.as_tensor(p).to(device=dev, dtype=torch.long).contiguous() for p in (primer, primer_root, primer_attr)]
+        per_clip = prim[0].dim() == 2
+        P = prim[0].shape[-1]
+        st = _lib.stream_ptr()
+        self._encode(h, sem, scene, motion, emotion, slice(0, B))
+        _lib.call("amt_generate_begin", h, B, _lib.ptr(prim[0]), _lib.ptr(prim[1]), _lib.ptr(prim[2]), P, int(per_clip),
+                  _lib.ptr(key), T, 0, int(max_conseq_N), int(max_conseq_chord), st)
+        ms = (C.c_double * 5)()
+        launches = (C.c_int64 * 5)()
+        nbytes = (C.c_int64 * 2)()
+        _lib.call("amt_generate_profile", h, -1, ms, launches, nbytes, st)
+        out = torch.empty(B, T, device=dev, dtype=torch.long)
+        _lib.call("amt_generate_end", h, _lib.ptr(out), st)
+        names = ("self_attn_decode", "cross_attn_decode", "decode_gemm", "sample", "empty_event_pair")
+        stats = {n: {"ms": ms[i], "launches": launches[i], "bytes": nbytes[i] if i < 2 else None} for i, n in enumerate(names)}
+        return out, stats
+
     def generate_batch(self, feature_semantic_list, feature_key, feature_scene_offset, feature_motion, feature_emotion,
                        primer, primer_root, primer_attr, target_seq_length=300, beam=0, beam_chance=1.0,
                        max_conseq_N=0, max_conseq_chord=2, sampler="categorical", return_logits=False):
