@@ -193,11 +193,11 @@ def main():
 
     # ---------------- G-gqa ----------------
     gq = {}
-    m = ref.gqa.MultiheadGQA(128, 8, 2).eval()
+    m = ref.gqa.MultiheadGQA(256, 8, 2).eval()        # head_dim 32, 4 query heads per kv head
     load_synthetic(m, seed=3)
     rs = np.random.RandomState(21)
     for L, B in ((6, 1), (6, 3), (64, 1), (64, 3)):
-        x = rs.standard_normal((L, B, 128)).astype(np.float32)
+        x = rs.standard_normal((L, B, 256)).astype(np.float32)
         gq[f"x_L{L}_B{B}"] = x
         for causal in (False, True):
             y, _ = m(t(x), t(x), t(x), is_causal=causal)

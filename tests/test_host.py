@@ -1,0 +1,115 @@
+"""Host-side logic that needs no GPU: module surface, flags, chord tables, sharding arithmetic, and
+that the C-ABI library loads and exports every symbol include/amt_hip.h declares."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import CFG1, CFG2, amt_named_shapes
+from video2music_amd import _lib, dist as vdist, synthetic
+from video2music_amd.model.video_music_transformer import VideoMusicTransformer
+from video2music_amd.utilities import constants as C
+from video2music_amd.utilities.argument_generate_funcs import parse_generate_args
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "amt_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(amt_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 25
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} is declared in include/amt_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert _lib.load().amt_abi_version() == 1
+
+
+def test_bad_config_is_rejected_without_a_gpu():
+    cfg = _lib.AmtConfig(6, 8, 500, 1024, 300, 300, 1287, 32)       # d_model not divisible by heads*... (500/8)
+    h = ctypes.c_void_p()
+    with pytest.raises(_lib.AmtError, match="amt_create"):
+        _lib.call("amt_create", ctypes.byref(cfg), ctypes.byref(h))
+    cfg = _lib.AmtConfig(6, 8, 512, 1024, 300, 300, 1287, 64)        # more than 32 clips per decode batch
+    with pytest.raises(_lib.AmtError, match="max_batch"):
+        _lib.call("amt_create", ctypes.byref(cfg), ctypes.byref(h))
+
+
+@pytest.mark.parametrize("cfg", [CFG1, CFG2])
+def test_state_dict_matches_reference_key_set(cfg):
+    m = VideoMusicTransformer(**cfg)
+    want = dict(amt_named_shapes(**cfg))
+    want["positional_encoding.pe"] = (cfg["max_sequence_chord"], 1, cfg["d_model"])
+    want["positional_encoding_video.pe"] = (300, 1, cfg["d_model"])
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert got == want
+    n_params = sum(p.numel() for p in m.parameters())
+    if cfg is CFG2:
+        assert abs(n_params - 33.4e6) < 1.0e6          # ~33 M parameters at config 2 (F=1287)
+    assert callable(m.transformer.generate_square_subsequent_mask)
+    mask = m.transformer.generate_square_subsequent_mask(3)
+    assert mask[0, 1] == float("-inf") and mask[1, 0] == 0
+
+
+def test_unsupported_constructor_options_raise():
+    with pytest.raises(NotImplementedError):
+        VideoMusicTransformer(total_vf_dim=1287, rpr=False)
+    with pytest.raises(NotImplementedError):
+        VideoMusicTransformer(total_vf_dim=1287, rpr=True, chord_embed=True)
+
+
+def test_no_cpu_fallback():
+    m = VideoMusicTransformer(**CFG1).eval()
+    z = torch.zeros(1, 2, dtype=torch.long)
+    with pytest.raises(_lib.AmtError, match="no CPU fallback"):
+        m(z, z, z, torch.zeros(1, 300, 768), torch.zeros(1), torch.zeros(1, 300), torch.zeros(1, 300, 512), torch.zeros(1, 300, 6))
+
+
+def test_chord_tables_and_primers():
+    assert C.CHORD_SIZE == 159 and C.CHORD_ROOT_SIZE == 15 and C.CHORD_ATTR_SIZE == 16
+    assert C.CHORD_DIC["C"] == 1 and C.CHORD_DIC["A:min"] == 122 and C.CHORD_INV_DIC["156"] == "B:maj7"
+    assert C.primer_from_name("C") == (1, 1, 0) and C.primer_from_name("A:min") == (122, 10, 5)
+    assert C.chord_to_root_attr(0) == (0, 1) and C.chord_to_root_attr(1) == (1, 1) and C.chord_to_root_attr(122) == (10, 5)
+    for i in range(1, C.CHORD_END):
+        r, a = C.chord_to_root_attr(i)
+        assert 1 + 13 * (r - 1) + (a - 1) == i
+
+
+def test_generate_flags_and_feature_widths():
+    args = parse_generate_args([])[0]
+    assert (args.target_seq_length_chord, args.beam, args.n_layers, args.num_heads, args.d_model, args.dim_feedforward) == (300, 0, 6, 8, 512, 1024)
+    assert (args.max_sequence_video, args.max_sequence_chord, args.motion_type, args.rpr) == (300, 300, 1, True)
+    from video2music_amd.generate import total_vf_dim_of, default_primer
+    assert total_vf_dim_of(args) == 1287 == synthetic.total_vf_dim(1)
+    args.motion_type = 0
+    assert total_vf_dim_of(args) == 776 == synthetic.total_vf_dim(0)
+    assert default_primer(0.0) == (1, 1, 0) and default_primer(1.0) == (122, 10, 5)
+
+
+def test_synthetic_recipes_are_reproducible():
+    a = synthetic.synthetic_features(2, seed=7)
+    b = synthetic.synthetic_features(2, seed=7)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert a["semantic"].shape == (2, 300, 768) and a["motion"].shape == (2, 300, 512) and a["emotion"].shape == (2, 300, 6)
+    assert np.allclose(a["emotion"].sum(-1), 1.0, atol=1e-5) and a["scene_offset"].min() == 0
+    assert np.array_equal(synthetic.fill_tensor("Wout.weight", (159, 128), 0), synthetic.fill_tensor("Wout.weight", (159, 128), 0))
+    er = synthetic.fill_tensor("transformer.decoder.layers.0.self_attn.Er", (300, 32), 0)
+    assert er.min() >= 0 and er.max() < 1
+    e = np.zeros((1, 300, 6), dtype=np.float32); e[0, 0, 2] = 1.0
+    assert synthetic.feature_key_from_emotion(e)[0] == 1.0       # generate.py:199-205 flat arg-max rule
+    e[:] = 0; e[0, 5, 2] = 1.0
+    assert synthetic.feature_key_from_emotion(e)[0] == 0.0
+
+
+def test_shard_bounds_cover_all_clips():
+    for n in (1, 7, 32, 256, 257):
+        for world in (1, 2, 3, 8):
+            spans = [vdist.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -79,14 +79,16 @@ def test_generate_g1_g2(golden, clip):
     assert np.array_equal(g2b.numpy(), g[f"g2_N1_c3_clip{clip}"])
 
 
+GQA_SHAPES = [("q_proj.weight", (256, 256)), ("q_proj.bias", (256,)), ("k_proj.weight", (64, 256)), ("k_proj.bias", (64,)),
+              ("v_proj.weight", (64, 256)), ("v_proj.bias", (64,)), ("norm.weight", (256,)), ("norm.bias", (256,)),
+              ("out_proj.weight", (256, 256)), ("out_proj.bias", (256,))]
+
+
 @pytest.mark.parametrize("L,B", [(6, 1), (6, 3), (64, 1), (64, 3)])
 @pytest.mark.parametrize("causal", [False, True])
 def test_gqa(golden, L, B, causal):
     g = golden("g_gqa.npz")
-    shapes = [("q_proj.weight", (128, 128)), ("q_proj.bias", (128,)), ("k_proj.weight", (32, 128)), ("k_proj.bias", (32,)),
-              ("v_proj.weight", (32, 128)), ("v_proj.bias", (32,)), ("norm.weight", (128,)), ("norm.bias", (128,)),
-              ("out_proj.weight", (128, 128)), ("out_proj.bias", (128,))]
-    sd = {k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=3).items()}
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(GQA_SHAPES, seed=3).items()}
     x = torch.from_numpy(g[f"x_L{L}_B{B}"])
     y = O.gqa_forward(x, x, x, sd, 8, 2, is_causal=causal)
     assert np.abs(y.numpy() - g[f"y_L{L}_B{B}_c{int(causal)}"]).max() < TOL

@@ -1,0 +1,92 @@
+"""``generate.py`` entry point for the AMT hot path (reference ``generate.py:86-392``).
+
+Reproduces the part of the reference script that feeds ``model.generate``: flag names/defaults
+(``parse_generate_args``), the ``total_vf_dim`` rule (:141-160), the batch-1 feature shapes
+(:181-189), the key rule (:199-207), the default primer ("C" / "A:min", :246-284) and the
+``model.generate`` keyword names (:368-392).  Everything after the chord ids (regression model,
+MIDI, FluidSynth, moviepy: :393-709) is out of scope.  Inputs come from ``--synthetic`` or from
+``.npy`` feature files; under torchrun the clips are sharded over ranks and the ids all-gathered.
+
+    python -m video2music_amd.generate --synthetic --n_clips 4 -target_seq_length_chord 64 -beam 0
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import dist as vdist
+from . import synthetic
+from .model.video_music_transformer import VideoMusicTransformer
+from .utilities import constants as C
+from .utilities.argument_generate_funcs import parse_generate_args
+from .utilities.device import get_device
+
+max_conseq_N = 0          # generate.py:65-66
+max_conseq_chord = 2
+
+
+def total_vf_dim_of(args, sem_dim=synthetic.SEM_DIM):
+    """generate.py:141-160."""
+    total = sem_dim if args.is_video else 0
+    total += 1
+    total += {0: 1, 1: 512, 2: 768}[args.motion_type]
+    total += 6 if args.emo_model.startswith("6c") else 5
+    return total
+
+
+def default_primer(feature_key):
+    """generate.py:246-269: "C" for a major key, "A:min" for a minor one; plain roots get attr 0."""
+    return C.primer_from_name("C" if int(feature_key) == 0 else "A:min")
+
+
+def main(argv=None):
+    args = parse_generate_args(argv)[0]
+    if args.music_gen_version is not None:
+        raise SystemExit("this build implements the base AMT (music_gen_version=None); V1/V2/V3 are SURVEY.md §8 row f1")
+    if args.force_cpu:
+        raise SystemExit("--force_cpu: video2music_amd has no CPU path (the CPU oracle lives in oracle/ for tests only)")
+    rank, world, local = vdist.init()
+    device = get_device()
+    if device.type != "cuda":
+        raise SystemExit("no GPU visible: video2music_amd runs on MI355X only")
+    model = VideoMusicTransformer(n_layers=args.n_layers, num_heads=args.num_heads, d_model=args.d_model,
+                                  dim_feedforward=args.dim_feedforward, max_sequence_midi=args.max_sequence_midi,
+                                  max_sequence_video=args.max_sequence_video, max_sequence_chord=args.max_sequence_chord,
+                                  total_vf_dim=total_vf_dim_of(args), rpr=args.rpr)
+    if args.synthetic:
+        shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+        sd = {k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=0).items()}
+        model.load_state_dict(sd, strict=False)
+        feats = synthetic.synthetic_features(args.n_clips, seed=args.seed, n_frames=args.max_sequence_video,
+                                             motion_type=args.motion_type)
+    else:
+        model.load_state_dict(torch.load(args.model_weights, map_location="cpu"))
+        raise SystemExit("dataset feature loading (dataset/vevo_dataset.py) is SURVEY.md §8 row f4; use --synthetic")
+    model = model.to(device).eval()
+    lo, hi = vdist.shard_bounds(args.n_clips, rank, world)
+    f = {k: torch.from_numpy(v[lo:hi]).to(device) for k, v in feats.items()}
+    prim = torch.tensor([default_primer(k) for k in feats["key"][lo:hi, 0]], device=device)
+    with torch.set_grad_enabled(False):
+        if args.beam > 1:
+            assert False, "No Beam sampling method implemented yet..."     # generate.py:347-349
+        print("RAND DIST" if args.beam == 0 else "BEAM: 1")
+        toks = model.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"],
+                                    prim[:, 0:1], prim[:, 1:2], prim[:, 2:3],
+                                    target_seq_length=args.target_seq_length_chord, beam=args.beam,
+                                    max_conseq_N=max_conseq_N, max_conseq_chord=max_conseq_chord, sampler=args.sampler)
+        toks = vdist.all_gather_sequences(toks, args.n_clips)
+    if rank == 0:
+        os.makedirs(args.output_dir, exist_ok=True)
+        out = toks.cpu().numpy()
+        for i, row in enumerate(out):
+            names = [C.chord_name(int(t)) for t in row]
+            with open(os.path.join(args.output_dir, f"clip{i:03d}_chords.lab"), "w") as fh:
+                fh.write("\n".join(f"{j} {n}" for j, n in enumerate(names)) + "\n")
+        print(json.dumps({"clips": int(out.shape[0]), "length": int(out.shape[1]), "first": out[0, :16].tolist()}))
+    return toks
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

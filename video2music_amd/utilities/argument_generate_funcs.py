@@ -1,0 +1,42 @@
+"""``parse_generate_args``: the flag names and defaults of the reference's
+``utilities/argument_generate_funcs.py:34-104`` that reach the AMT hot path, plus ``--synthetic``
+inputs (the reference tree ships neither weights nor dataset features)."""
+import argparse
+
+from .constants import IS_VIDEO, RPR, VERSION
+
+
+def parse_generate_args(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument("-dataset_dir", type=str, default="./dataset/", help="Folder of VEVO dataset")
+    parser.add_argument("-output_dir", type=str, default="./output_vevo/" + VERSION, help="Folder to write generated chords to")
+    parser.add_argument("-primer_file", type=str, default=None)
+    parser.add_argument("--force_cpu", action="store_true", help="Kept for flag compatibility; this build has no CPU path")
+    parser.add_argument("-target_seq_length_chord", type=int, default=300, help="Target length of the chord sequence")
+    parser.add_argument("-num_prime_chord", type=int, default=30)
+    parser.add_argument("-model_weights", type=str, default="saved_models/AMT/best_loss_weights.pickle",
+                        help="state_dict saved with torch.save (reference key names)")
+    parser.add_argument("-beam", type=int, default=0, help="0 for random probability sample and 1 for greedy")
+    parser.add_argument("-max_sequence_midi", type=int, default=2048)
+    parser.add_argument("-max_sequence_video", type=int, default=300)
+    parser.add_argument("-max_sequence_chord", type=int, default=300)
+    parser.add_argument("-chord_embed", type=bool, default=True)
+    parser.add_argument("-n_layers", type=int, default=6)
+    parser.add_argument("-num_heads", type=int, default=8)
+    parser.add_argument("-d_model", type=int, default=512)
+    parser.add_argument("-dim_feedforward", type=int, default=1024)
+    parser.add_argument("-rms_norm", type=bool, default=False)
+    parser.add_argument("-music_gen_version", type=str, default=None,
+                        help="None selects the base AMT (VideoMusicTransformer), the model of this build; "
+                             "the reference default '2.2' selects VideoMusicTransformer_V2 (SURVEY.md §8 f1, not built yet)")
+    parser.add_argument("-scene_embed", type=bool, default=False)
+    parser.add_argument("-is_video", type=bool, default=IS_VIDEO)
+    parser.add_argument("-emo_model", type=str, default="6c_l14p")
+    parser.add_argument("-motion_type", type=int, default=1, help="0 as original, 1 as option 1, 2 as option 2")
+    parser.add_argument("-rpr", type=bool, default=RPR)
+    # additions of this build
+    parser.add_argument("--synthetic", action="store_true", help="random-init procedural weights and random video features")
+    parser.add_argument("--n_clips", type=int, default=1, help="clips to generate for (sharded over ranks under torchrun)")
+    parser.add_argument("--sampler", type=str, default="categorical", choices=["categorical", "argmax"])
+    parser.add_argument("--seed", type=int, default=1234)
+    return parser.parse_known_args(argv)
