@@ -69,6 +69,63 @@ def cpu_baseline(cfg, sd, T, budget_s=25.0):
             "host_cpus": os.cpu_count()}
 
 
+def roofline(model, f, prim, B, T, cfg):
+    """Roofline of the dominant decode kernel (the K/V-streaming relative-position self-attention).
+
+    Primary measurement: one full generate is replayed eagerly with a HIP event pair recorded on the
+    launch stream around EVERY kernel launch (amt_generate_profile); the mean pair time minus the
+    mean time of an empty pair is the kernel's average launch duration.  achieved = algorithmic fp32
+    K/V bytes per launch / that duration.  `in_situ` adds the cost of the kernel inside the captured
+    step graph: (generate ms - generate ms with the kernel left out of the graph) / launches.
+    """
+    with torch.no_grad():
+        _, st = model.generate_profile(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], *prim,
+                                       target_seq_length=T)
+
+        def timed(mask):
+            model._debug_set_skip(mask)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            model.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], *prim,
+                                 target_seq_length=T, beam=0, sampler="argmax")
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b)
+
+        for m in (0, 1, 2):
+            timed(m)                                         # graph capture / warm-up per variant
+        rounds = [[timed(m) for m in (0, 1, 2)] for _ in range(3)]
+        model._debug_set_skip(0)
+    empty_us = 1e3 * st["empty_event_pair"]["ms"] / st["empty_event_pair"]["launches"]
+
+    def avg_us(k):
+        return max(1e3 * st[k]["ms"] / st[k]["launches"] - empty_us, 1e-3)
+
+    def gbs(k):
+        return st[k]["bytes"] / st[k]["launches"] / avg_us(k) / 1e3
+
+    full, no_self, no_cross = (float(np.median([r[i] for r in rounds])) for i in range(3))
+    n = st["self_attn_decode"]["launches"]
+    return {
+        "bound": "hbm", "kernel": "attn_decode_kernel<64, true> (relative-position self-attention, decode step)",
+        "achieved": round(gbs("self_attn_decode"), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(gbs("self_attn_decode") / HBM_PEAK_GBS, 4), "traffic": None,
+        "launches": n, "avg_launch_us": round(avg_us("self_attn_decode"), 3),
+        "algorithmic_bytes_per_launch": round(st["self_attn_decode"]["bytes"] / n),
+        "measured": "HIP event pair on the launch stream around every launch of an eager replay of one full generate, "
+                    f"minus the empty-pair cost ({empty_us:.2f} us)",
+        "second_kernel": {"kernel": "attn_decode_kernel<64, false> (cross-attention over video K/V, decode step)",
+                          "achieved": round(gbs("cross_attn_decode"), 1), "frac": round(gbs("cross_attn_decode") / HBM_PEAK_GBS, 4),
+                          "avg_launch_us": round(avg_us("cross_attn_decode"), 3),
+                          "algorithmic_bytes_per_launch": round(st["cross_attn_decode"]["bytes"] / n)},
+        "other_kernels_avg_us": {k: round(avg_us(k), 3) for k in ("decode_gemm", "sample")},
+        "in_situ": {"method": "generate ms minus generate ms with the kernel left out of the step graph, per launch; "
+                              "median of 3 interleaved rounds",
+                    "generate_ms": {"full": round(full, 2), "without_self_attn": round(no_self, 2), "without_cross_attn": round(no_cross, 2)},
+                    "self_attn_us": round(1e3 * (full - no_self) / n, 3), "cross_attn_us": round(1e3 * (full - no_cross) / n, 3)},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,32 +188,7 @@ def main():
                    "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}"},
     }
     if rank == 0 and world == 1 and not args.no_roofline:
-        with torch.no_grad():
-            _, st = model.generate_profile(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], pr, prr, pra,
-                                           target_seq_length=T)
-        empty_us = 1e3 * st["empty_event_pair"]["ms"] / st["empty_event_pair"]["launches"]
-
-        def avg_us(k):           # event-pair time minus the cost of an empty pair
-            return max(1e3 * st[k]["ms"] / st[k]["launches"] - empty_us, 1e-3)
-
-        def gbs(k):
-            return st[k]["bytes"] / st[k]["launches"] / (avg_us(k) * 1e-6) / 1e9
-
-        names = {"self_attn_decode": "attn_decode_kernel<64, true> (relative-position self-attention)",
-                 "cross_attn_decode": "attn_decode_kernel<64, false> (cross-attention over video K/V)"}
-        dom = max(names, key=lambda k: avg_us(k) * st[k]["launches"])
-        other = [k for k in names if k != dom][0]
-        result["roofline"] = {
-            "bound": "hbm", "kernel": names[dom], "achieved": round(gbs(dom), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gbs(dom) / HBM_PEAK_GBS, 4), "traffic": None,
-            "launches": st[dom]["launches"], "avg_launch_us": round(avg_us(dom), 3),
-            "algorithmic_bytes_per_launch": round(st[dom]["bytes"] / st[dom]["launches"]),
-            "measured": "HIP event pair on the launch stream around every launch of an eager replay of one full generate, "
-                        f"minus the empty-pair cost ({empty_us:.2f} us)",
-            "second_kernel": {"kernel": names[other], "achieved": round(gbs(other), 1), "avg_launch_us": round(avg_us(other), 3),
-                              "algorithmic_bytes_per_launch": round(st[other]["bytes"] / st[other]["launches"])},
-            "other_kernels_avg_us": {k: round(avg_us(k), 3) for k in ("decode_gemm", "sample")},
-        }
+        result["roofline"] = roofline(model, f, (pr, prr, pra), B, T, cfg)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, sd, T)
     if rank == 0:

@@ -108,6 +108,10 @@ int32_t amt_generate(amt_handle* h, int32_t B, const int64_t* primer, const int6
                      const int64_t* primer_attr, int32_t P, int32_t primer_per_clip, const float* key,
                      int32_t T, int32_t beam, int32_t max_conseq_N, int32_t max_conseq_chord,
                      int64_t* tokens_out, float* logits_out, void* stream);
+/* Measurement aid for bench.py (results become meaningless): leaves the self-attention (bit 0) and/or
+ * cross-attention (bit 1) launches out of the decode step, so that the in-situ cost of a kernel is
+ * the difference between two timed generates.  0 restores the real step. */
+int32_t amt_debug_set_skip(amt_handle* h, int32_t mask);
 /* Timing/roofline introspection for bench.py: algorithmic HBM bytes of the decode-attention
  * launches of one step at key count n_keys (self) — see DESIGN.md. */
 int64_t amt_decode_step_bytes(const amt_handle* h, int32_t B, int32_t n_self_keys, int32_t S);

@@ -84,9 +84,10 @@ struct amt_handle {
     int64_t *tokens = nullptr, *roots = nullptr, *attrs = nullptr;   // [maxB][Tcap]
     // current generation
     int genB = 0, genT = 0, genP = 0, beam = 0, mcN = 0, mcC = 2, steps_done = 0;
+    int skip_mask = 0;                   // bench-only ablation: 1 = no self-attention launches, 2 = no cross-attention launches
     bool gen_active = false;
     // graphs keyed by the parameters baked into the captured kernel arguments
-    struct GraphKey { int B, T, P, beam, mcN, mcC, S, nsteps; float* logits; };
+    struct GraphKey { int B, T, P, beam, mcN, mcC, S, nsteps, skip, pad; float* logits; };
     struct GraphEntry { GraphKey key; hipGraphExec_t exec; hipGraph_t graph; };
     std::vector<GraphEntry> graphs;
     hipStream_t cap_stream = nullptr;    // capture-only stream (the caller's may be the legacy null stream)
@@ -222,9 +223,11 @@ int32_t enqueue_decoder_step(amt_handle* h, hipStream_t s, StepProf* prof = null
         AttnDecodeParams a{};
         a.q = h->qb; a.k = Kc; a.v = Vc; a.o = h->ob; a.B = B; a.H = H; a.hd = hd; a.cap = h->Tcap;
         a.pos = h->pos; a.Er = L.Er; a.er_len = h->Tcap;
-        PROF_BEGIN();
-        if ((rc = amt_launch_attn_decode(a, s))) return rc;
-        PROF_END(0);
+        if (!(h->skip_mask & 1)) {
+            PROF_BEGIN();
+            if ((rc = amt_launch_attn_decode(a, s))) return rc;
+            PROF_END(0);
+        }
         // K3: out-proj + residual
         DecodeGemmParams o{};
         o.B = B; o.eps = LN_EPS; o.scale = 1.f; o.x = h->ob; o.ldx = d; o.Wp = L.p_sao; o.bias = L.sa_ob; o.N = d; o.K = d;
@@ -242,9 +245,11 @@ int32_t enqueue_decoder_step(amt_handle* h, hipStream_t s, StepProf* prof = null
         // K5: cross-attention over the clip's video keys
         AttnDecodeParams x{};
         x.q = h->qb; x.k = Kx; x.v = Vx; x.o = h->ob; x.B = B; x.H = H; x.hd = hd; x.cap = h->Scap; x.n_keys = h->encS;
-        PROF_BEGIN();
-        if ((rc = amt_launch_attn_decode(x, s))) return rc;
-        PROF_END(1);
+        if (!(h->skip_mask & 2)) {
+            PROF_BEGIN();
+            if ((rc = amt_launch_attn_decode(x, s))) return rc;
+            PROF_END(1);
+        }
         // K6: out-proj + residual
         DecodeGemmParams o2{};
         o2.B = B; o2.eps = LN_EPS; o2.scale = 1.f; o2.x = h->ob; o2.ldx = d; o2.Wp = L.p_cao; o2.bias = L.ca_ob; o2.N = d; o2.K = d;
@@ -271,7 +276,7 @@ int32_t enqueue_decoder_step(amt_handle* h, hipStream_t s, StepProf* prof = null
 }
 
 int32_t get_graph(amt_handle* h, int nsteps, float* logits_out, hipGraphExec_t* out) {
-    amt_handle::GraphKey key{h->genB, h->genT, h->genP, h->beam, h->mcN, h->mcC, h->encS, nsteps, logits_out};
+    amt_handle::GraphKey key{h->genB, h->genT, h->genP, h->beam, h->mcN, h->mcC, h->encS, nsteps, h->skip_mask, 0, logits_out};
     for (auto& g : h->graphs)
         if (memcmp(&g.key, &key, sizeof(key)) == 0) { *out = g.exec; return 0; }
     hipGraph_t graph;
@@ -713,6 +718,12 @@ extern "C" int32_t amt_generate(amt_handle* h, int32_t B, const int64_t* primer,
     if (rc) return rc;
     if ((rc = amt_generate_run(h, -1, logits_out, stream))) return rc;
     return amt_generate_end(h, tokens_out, stream);
+}
+
+extern "C" int32_t amt_debug_set_skip(amt_handle* h, int32_t mask) {
+    AMT_CHECK_ARG(h && mask >= 0 && mask < 4, "amt_debug_set_skip: bad argument");
+    h->skip_mask = mask;
+    return 0;
 }
 
 extern "C" int64_t amt_decode_step_bytes(const amt_handle* h, int32_t B, int32_t n_self_keys, int32_t S) {

@@ -56,6 +56,21 @@ __global__ __launch_bounds__(NWS * 64) void sample_kernel(SampleParams p) {
     const int d = p.d;
     const int t = *p.pos, cur = t + 1;
 
+    // Wout rows of the first pass do not depend on the LayerNorm: put them in flight now
+    constexpr int RB = KCH <= 2 ? 10 : (KCH == 3 ? 5 : 4);    // rows per wave and pass (16 waves x 10 rows cover the 159 outputs at once)
+    float4 wv[RB][KCH];
+    float bo[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        const int n = wave + j * NWS;
+        bo[j] = n < V ? p.bout[n] : 0.f;
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            const int i = (c * 64 + lane) * 4;
+            wv[j][c] = (n < V && i < d) ? ld4(p.Wout + (size_t)n * d + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+
     // ---- LayerNorm(s) of the row, by wave 0 (d <= 1024: up to 4 float4 per lane) ----
     if (wave == 0) {
         const float inv_d = 1.0f / (float)d;
@@ -102,10 +117,8 @@ __global__ __launch_bounds__(NWS * 64) void sample_kernel(SampleParams p) {
     }
     __syncthreads();
 
-    // ---- logits = y . Wout^T + b : wave w takes rows w, w+8, ...; RB rows are in flight at once so
-    //      the L2 round trips of the weight rows overlap (d <= 1024: up to 4 float4 per lane and row) ----
+    // ---- logits = y . Wout^T + b : wave w takes rows w, w+16, ... ----
     {
-        constexpr int RB = 5;
         float4 yv[KCH];
 #pragma unroll
         for (int c = 0; c < KCH; ++c) {
@@ -113,14 +126,16 @@ __global__ __launch_bounds__(NWS * 64) void sample_kernel(SampleParams p) {
             yv[c] = (i < d) ? ld4(&ys[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         for (int n0 = wave; n0 < V; n0 += NWS * RB) {
-            float4 wv[RB][KCH];
+            if (n0 != wave) {                         // later passes (d > 512 only): reload
 #pragma unroll
-            for (int j = 0; j < RB; ++j) {
-                const int n = n0 + j * NWS;
+                for (int j = 0; j < RB; ++j) {
+                    const int n = n0 + j * NWS;
+                    bo[j] = n < V ? p.bout[n] : 0.f;
 #pragma unroll
-                for (int c = 0; c < KCH; ++c) {
-                    const int i = (c * 64 + lane) * 4;
-                    wv[j][c] = (n < V && i < d) ? ld4(p.Wout + (size_t)n * d + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int c = 0; c < KCH; ++c) {
+                        const int i = (c * 64 + lane) * 4;
+                        wv[j][c] = (n < V && i < d) ? ld4(p.Wout + (size_t)n * d + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
                 }
             }
 #pragma unroll
@@ -131,7 +146,7 @@ __global__ __launch_bounds__(NWS * 64) void sample_kernel(SampleParams p) {
                 for (int c = 0; c < KCH; ++c)
                     sdot += wv[j][c].x * yv[c].x + wv[j][c].y * yv[c].y + wv[j][c].z * yv[c].z + wv[j][c].w * yv[c].w;
                 sdot = wave_sum(sdot);
-                if (lane == 0 && n < V) logit[n] = sdot + p.bout[n];
+                if (lane == 0 && n < V) logit[n] = sdot + bo[j];
             }
         }
     }

@@ -280,6 +280,10 @@ class VideoMusicTransformer(nn.Module):
                                    feature_emotion, primer, primer_root, primer_attr, target_seq_length, beam,
                                    beam_chance, max_conseq_N, max_conseq_chord, sampler)[:1]
 
+    def _debug_set_skip(self, mask):
+        """bench.py only: leave the self- (1) / cross- (2) attention launches out of the decode step."""
+        _lib.call("amt_debug_set_skip", self._ensure_handle(), int(mask))
+
     def generate_profile(self, feature_semantic_list, feature_key, feature_scene_offset, feature_motion, feature_emotion,
                          primer, primer_root, primer_attr, target_seq_length=300, max_conseq_N=0, max_conseq_chord=2):
         """One feedback-greedy generate (<= 32 clips) issued eagerly with HIP events around every
