@@ -45,6 +45,10 @@ def cpu_baseline(cfg, sd, T, budget_s=25.0):
     """Per-length cost of one step of the reference loop (full re-forward incl. encoder, no KV
     cache, B=1: model/video_music_transformer.py:1069-1071) integrated over the T-1 steps of a clip."""
     from oracle import amt_oracle as O
+    prev_threads = torch.get_num_threads()
+    # the GPU box gives one GPU a 16-CPU share; more intra-op threads only add overhead at these sizes
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     feats = synthetic.synthetic_features(1, seed=99)
     f = {k: torch.from_numpy(v) for k, v in feats.items()}
     lengths = [1, T // 8, T // 4, T // 2, (3 * T) // 4, T - 1]
@@ -63,7 +67,8 @@ def cpu_baseline(cfg, sd, T, budget_s=25.0):
                 reps += 1
             cost.append(best)
     per_clip = float(np.trapezoid(np.interp(np.arange(1, T), lengths, cost)))
-    return {"value": round((T - 1) / per_clip, 3), "unit": "chord-tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+    torch.set_num_threads(prev_threads)
+    return {"value": round((T - 1) / per_clip, 3), "unit": "chord-tokens/s", "cores": threads, "kind": "port",
             "sample": f"oracle forward (no KV cache, encoder re-run, B=1) timed at L={lengths} (best of 2-3), "
                       f"integrated over the {T - 1} steps of one clip = {per_clip:.1f} s/clip; clips run sequentially",
             "host_cpus": os.cpu_count()}
