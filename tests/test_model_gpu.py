@@ -184,3 +184,20 @@ def test_full_size_generate_properties():
         fwd = m(tc, roots.cuda(), attrs.cuda(), f["semantic"][sub], f["key"][sub], f["scene_offset"][sub], f["motion"][sub], f["emotion"][sub])
     err = (fwd[:, :T - 1].permute(1, 0, 2) - dec_logits[:T - 1, sub]).abs().max().item()
     assert err < 5e-4, err
+
+
+def test_weight_reload_is_picked_up_by_captured_graphs():
+    """load_state_dict after a generate: the repacked decode weights must be the ones the (already captured)
+    step graph reads."""
+    m, _ = build(CFG1, seed=0)
+    f = cu(feats_t(synthetic.synthetic_features(2, seed=21)))
+    kw = dict(primer=torch.tensor([1]), primer_root=torch.tensor([1]), primer_attr=torch.tensor([0]),
+              target_seq_length=32, beam=0, sampler="argmax")
+    a0 = m.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], **kw)
+    sd1 = synthetic_sd(CFG1, seed=5)
+    m.load_state_dict(sd1, strict=False)
+    a1 = m.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], **kw)
+    fresh, _ = build(CFG1, seed=5)
+    b1 = fresh.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], **kw)
+    assert torch.equal(a1, b1)
+    assert not torch.equal(a0, a1)

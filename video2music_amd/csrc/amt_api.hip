@@ -124,8 +124,10 @@ int32_t need(amt_handle* h, const std::string& name, std::initializer_list<int64
 }
 
 int32_t pack(amt_handle* h, const float* w, int N, int K, float** out, hipStream_t s) {
-    int32_t rc = dev_alloc(h, out, (size_t)cdiv(N, 16) * 16 * K);
-    if (rc) return rc;
+    if (!*out) {                         // re-finalize after a weight reload repacks into the same buffer,
+        int32_t rc = dev_alloc(h, out, (size_t)cdiv(N, 16) * 16 * K);   // so captured graphs stay valid
+        if (rc) return rc;
+    }
     return amt_launch_pack_weight(w, *out, N, K, s);
 }
 
@@ -375,8 +377,8 @@ extern "C" int32_t amt_finalize(amt_handle* h) {
     if ((rc = need(h, "positional_encoding.pe", {h->Tcap, 1, d}, &h->pe))) return rc;
     if ((rc = need(h, "positional_encoding_video.pe", {h->Scap, 1, d}, &h->pe_v))) return rc;
 
-    h->enc.assign(h->nl, EncLayer{});
-    h->dec.assign(h->nl, DecLayer{});
+    if ((int)h->enc.size() != h->nl) h->enc.assign(h->nl, EncLayer{});
+    if ((int)h->dec.size() != h->nl) h->dec.assign(h->nl, DecLayer{});      // keeps the packed buffers across re-finalize
     for (int l = 0; l < h->nl; ++l) {
         const std::string e = "transformer.encoder.layers." + std::to_string(l) + ".";
         EncLayer& E = h->enc[l];
@@ -459,14 +461,12 @@ extern "C" int32_t amt_finalize(amt_handle* h) {
     if ((rc = amt_launch_gemm(gemm_params(Eattr, (int)d, h->Wc_main, (int)d, h->PA, (int)d, 16, (int)d, (int)d, nullptr), s))) return rc;
     for (int l = 0; l < h->nl; ++l) {
         DecLayer& D = h->dec[l];
-        if (!D.p_sa) {
-            if ((rc = pack(h, D.sa_w, 3 * (int)d, (int)d, &D.p_sa, s))) return rc;
-            if ((rc = pack(h, D.sa_ow, (int)d, (int)d, &D.p_sao, s))) return rc;
-            if ((rc = pack(h, D.ca_w, (int)d, (int)d, &D.p_caq, s))) return rc;      // q rows 0:d of the packed in-proj
-            if ((rc = pack(h, D.ca_ow, (int)d, (int)d, &D.p_cao, s))) return rc;
-            if ((rc = pack(h, D.l1w, (int)dff, (int)d, &D.p_l1, s))) return rc;
-            if ((rc = pack(h, D.l2w, (int)d, (int)dff, &D.p_l2, s))) return rc;
-        }
+        if ((rc = pack(h, D.sa_w, 3 * (int)d, (int)d, &D.p_sa, s))) return rc;
+        if ((rc = pack(h, D.sa_ow, (int)d, (int)d, &D.p_sao, s))) return rc;
+        if ((rc = pack(h, D.ca_w, (int)d, (int)d, &D.p_caq, s))) return rc;      // q rows 0:d of the packed in-proj
+        if ((rc = pack(h, D.ca_ow, (int)d, (int)d, &D.p_cao, s))) return rc;
+        if ((rc = pack(h, D.l1w, (int)dff, (int)d, &D.p_l1, s))) return rc;
+        if ((rc = pack(h, D.l2w, (int)d, (int)dff, &D.p_l2, s))) return rc;
     }
     AMT_HIP(hipDeviceSynchronize());
     // captured graphs hold pointers that stay valid (weights reload in place), nothing to invalidate
