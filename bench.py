@@ -51,7 +51,7 @@ def cpu_baseline(cfg, sd, T, budget_s=25.0):
     torch.set_num_threads(threads)
     feats = synthetic.synthetic_features(1, seed=99)
     f = {k: torch.from_numpy(v) for k, v in feats.items()}
-    lengths = [1, T // 8, T // 4, T // 2, (3 * T) // 4, T - 1]
+    lengths = sorted({1, T // 16, T // 8, T // 4, (3 * T) // 8, T // 2, (5 * T) // 8, (3 * T) // 4, (7 * T) // 8, T - 1})
     rs = np.random.RandomState(0)
     cost = []
     t_start = time.time()
@@ -111,10 +111,16 @@ def roofline(model, f, prim, B, T, cfg):
 
     full, no_self, no_cross = (float(np.median([r[i] for r in rounds])) for i in range(3))
     n = st["self_attn_decode"]["launches"]
+    # HBM traffic per launch from the committed PMC pass (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE),
+    # expressed as a ratio to the algorithmic bytes of the same launches; counters cannot be read from inside bench.py
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_attn_traffic.json")
+    if os.path.exists(pmc) and cfg["d_model"] == 512:
+        traffic = round(json.load(open(pmc))["self_attn"]["traffic_over_algorithmic"] * st["self_attn_decode"]["bytes"] / n)
     return {
         "bound": "hbm", "kernel": "attn_decode_kernel<64, true> (relative-position self-attention, decode step)",
         "achieved": round(gbs("self_attn_decode"), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(gbs("self_attn_decode") / HBM_PEAK_GBS, 4), "traffic": None,
+        "frac": round(gbs("self_attn_decode") / HBM_PEAK_GBS, 4), "traffic": traffic,
         "launches": n, "avg_launch_us": round(avg_us("self_attn_decode"), 3),
         "algorithmic_bytes_per_launch": round(st["self_attn_decode"]["bytes"] / n),
         "measured": "HIP event pair on the launch stream around every launch of an eager replay of one full generate, "

@@ -14,7 +14,7 @@ seg = rows[last:]
 res = {"n_kernels": len(seg), "span_ms": (seg[-1][1] - seg[0][0]) / 1e6}
 agg = {}
 for s, e, n in seg:
-    k = n.split("(")[0][-60:]
+    k = n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
     a = agg.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += (e - s) / 1e3
 res["kernels"] = {k: {"calls": v[0], "avg_us": round(v[1] / v[0], 3), "total_ms": round(v[1] / 1e3, 2)} for k, v in agg.items()}
 selfk = [(e - s) / 1e3 for s, e, n in seg if "attn_decode_kernel<64, true" in n]
