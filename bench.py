@@ -152,7 +152,7 @@ def main():
 
     rank, world, local = vdist.init()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", local % torch.cuda.device_count())    # ranks share a GPU only in gloo rehearsals
     torch.cuda.set_device(device)
     B, T = args.batch, args.seq
     heads = 8 if args.d_model >= 512 else 4
@@ -170,6 +170,7 @@ def main():
         return vdist.all_gather_sequences(toks, world * B)
 
     def barrier():
+        torch.cuda.synchronize(device)
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(device)
@@ -184,7 +185,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
     if world > 1:
-        te = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        te = torch.tensor([elapsed], dtype=torch.float64, device=device if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(te, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(te)
     assert out.shape == (world * B, T)

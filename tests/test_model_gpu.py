@@ -201,3 +201,74 @@ def test_weight_reload_is_picked_up_by_captured_graphs():
     b1 = fresh.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], **kw)
     assert torch.equal(a1, b1)
     assert not torch.equal(a0, a1)
+
+
+def test_long_primer_short_video_and_batch_slicing(model1):
+    """Edge cases: a 4-chord primer (generate.py's custumPrimer path), a clip shorter than max_sequence_video,
+    and a batch larger than the 32-clip decode slice."""
+    m, sd = model1
+    # (1) primer C, A:min, D:min, G with per-chord root/attr as generate.py:286-339 encodes them
+    names = ["C", "A:min", "D:min", "G"]
+    prim = torch.tensor([C.primer_from_name(n) for n in names])          # (4, 3): id, root, attr
+    feats = synthetic.synthetic_features(1, seed=31)
+    fc = feats_t(feats)
+    f = cu(fc)
+    T = 24
+    out = m.generate(f["semantic"], f["key"][0], f["scene_offset"], f["motion"], f["emotion"], prim[:, 0], prim[:, 1], prim[:, 2],
+                     target_seq_length=T, beam=0, sampler="argmax")
+    ref = O.generate(sd, 4, fc["semantic"], fc["key"], fc["scene_offset"], fc["motion"], fc["emotion"],
+                     prim[:, 0], prim[:, 1], prim[:, 2], target_seq_length=T, beam=0)
+    assert torch.equal(out.cpu(), ref) and out[0, :4].tolist() == prim[:, 0].tolist()
+    g1 = m.generate(f["semantic"], f["key"][0], f["scene_offset"], f["motion"], f["emotion"], prim[:, 0], prim[:, 1], prim[:, 2],
+                    target_seq_length=T, beam=1)
+    ref1 = O.generate(sd, 4, fc["semantic"], fc["key"], fc["scene_offset"], fc["motion"], fc["emotion"],
+                      prim[:, 0], prim[:, 1], prim[:, 2], target_seq_length=T, beam=1)
+    assert torch.equal(g1.cpu(), ref1)
+    # (2) 120-frame clip (the key capacity of the cross-attention stays 300)
+    S = 120
+    fs = {k: (v[:, :S].contiguous() if v.dim() > 1 and v.shape[1] == 300 else v) for k, v in fc.items()}
+    root = torch.tensor([[1, 10, 3, 8, 14, 14]])
+    attr = torch.tensor([[0, 5, 5, 0, 15, 15]])
+    ref_logits = O.forward(sd, 4, root, attr, fs["semantic"], fs["key"], fs["scene_offset"], fs["motion"], fs["emotion"])
+    fsc = cu(fs)
+    with torch.no_grad():
+        got = m(root, root.cuda(), attr.cuda(), fsc["semantic"], fsc["key"], fsc["scene_offset"], fsc["motion"], fsc["emotion"])
+    assert (got.cpu() - ref_logits).abs().max().item() < LOGIT_TOL
+    out_s = m.generate(fsc["semantic"], fsc["key"][0], fsc["scene_offset"], fsc["motion"], fsc["emotion"], prim[:1, 0], prim[:1, 1], prim[:1, 2],
+                       target_seq_length=12, beam=0, sampler="argmax")
+    ref_s = O.generate(sd, 4, fs["semantic"], fs["key"], fs["scene_offset"], fs["motion"], fs["emotion"],
+                       prim[:1, 0], prim[:1, 1], prim[:1, 2], target_seq_length=12, beam=0)
+    assert torch.equal(out_s.cpu(), ref_s)
+    # (3) 35 clips: two decode slices (32 + 3); every clip equals its B=1 run
+    f35 = cu(feats_t(synthetic.synthetic_features(35, seed=32)))
+    toks = m.generate_batch(f35["semantic"], f35["key"], f35["scene_offset"], f35["motion"], f35["emotion"], prim[:1, 0], prim[:1, 1], prim[:1, 2],
+                            target_seq_length=16, beam=0, sampler="argmax")
+    assert toks.shape == (35, 16)
+    for b in (0, 31, 32, 34):
+        sl = slice(b, b + 1)
+        one = m.generate_batch(f35["semantic"][sl], f35["key"][sl], f35["scene_offset"][sl], f35["motion"][sl], f35["emotion"][sl],
+                               prim[:1, 0], prim[:1, 1], prim[:1, 2], target_seq_length=16, beam=0, sampler="argmax")
+        assert torch.equal(one[0], toks[b])
+    rs = np.random.RandomState(3)
+    root35 = torch.from_numpy(rs.randint(0, 13, size=(35, 5))).cuda()
+    attr35 = torch.from_numpy(rs.randint(0, 14, size=(35, 5))).cuda()
+    with torch.no_grad():
+        lg = m(root35, root35, attr35, f35["semantic"], f35["key"], f35["scene_offset"], f35["motion"], f35["emotion"])
+        lg1 = m(root35[33:34], root35[33:34], attr35[33:34], f35["semantic"][33:34], f35["key"][33:34], f35["scene_offset"][33:34],
+                f35["motion"][33:34], f35["emotion"][33:34])
+    assert (lg[33:34] - lg1).abs().max().item() < 1e-5
+
+
+def test_scalar_motion_feature_width():
+    """motion_type 0: feature_motion is (B,S) and total_vf_dim = 776 (generate.py:146-149, forward :1012-1015)."""
+    cfg = dict(CFG1, total_vf_dim=synthetic.total_vf_dim(0))
+    m, sd = build(cfg, seed=2)
+    fc = feats_t(synthetic.synthetic_features(2, seed=8, motion_type=0))
+    assert fc["motion"].shape == (2, 300)
+    root = torch.tensor([[1, 2, 3], [4, 5, 6]])
+    attr = torch.tensor([[1, 0, 2], [3, 4, 5]])
+    ref = O.forward(sd, 4, root, attr, fc["semantic"], fc["key"], fc["scene_offset"], fc["motion"], fc["emotion"])
+    f = cu(fc)
+    with torch.no_grad():
+        got = m(root, root.cuda(), attr.cuda(), f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"])
+    assert (got.cpu() - ref).abs().max().item() < LOGIT_TOL

@@ -297,6 +297,11 @@ int32_t get_graph(amt_handle* h, int nsteps, float* logits_out, hipGraphExec_t* 
     AMT_HIP(e);
     hipGraphExec_t exec;
     AMT_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    if (h->graphs.size() >= 32) {        // bound the cache (each distinct logits_out pointer is a new key)
+        (void)hipGraphExecDestroy(h->graphs.front().exec);
+        (void)hipGraphDestroy(h->graphs.front().graph);
+        h->graphs.erase(h->graphs.begin());
+    }
     h->graphs.push_back({key, exec, graph});
     *out = exec;
     return 0;

@@ -17,11 +17,14 @@ def env_rank_world():
 
 
 def init(backend=None):
-    """Initialises the default process group from the torchrun environment (no-op for world size 1)."""
+    """Initialises the default process group from the torchrun environment (no-op for world size 1).
+
+    ``AMT_DIST_BACKEND=gloo`` forces gloo (rehearsals of the multi-rank path on a box with fewer GPUs
+    than ranks; ids are then staged through host memory for the gather)."""
     rank, world, local = env_rank_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("AMT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             torch.cuda.set_device(local)
@@ -44,6 +47,8 @@ def all_gather_sequences(tokens, n_clips=None):
     the largest shard for the collective and trimmed afterwards."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return tokens
+    if tokens.is_cuda and dist.get_backend() == "gloo":      # rehearsal path: gloo gathers host tensors
+        return all_gather_sequences(tokens.cpu(), n_clips).to(tokens.device)
     world = dist.get_world_size()
     sizes = [torch.zeros(1, dtype=torch.long, device=tokens.device) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([tokens.shape[0]], dtype=torch.long, device=tokens.device))
