@@ -164,6 +164,18 @@ int32_t amt_moe_fwd(const float* x, const float* gate_w, const float* gate_b,
                     float* out, int32_t* idx_out, float* w_out, float* scratch,
                     int32_t n_tok, int32_t d, int32_t dff, int32_t n_exp, void* stream);
 
+/* Pieces of the same layer for expert-parallel execution (config 5: one expert group per GPU; the token rows
+ * travel by all_to_all between amt_moe_route_fwd and amt_moe_combine_fwd, see video2music_amd/model/moe.py):
+ * router (moe.py:180-190), one GLUExpert on n rows (moe.py:44-49; scratch >= 2*n*dff floats), and the
+ * weighted sum out[t] = w0*y[slot_pos[t,0]] + w1*y[slot_pos[t,1]] in expert-index order (+ shared_scale*shared). */
+int32_t amt_moe_route_fwd(const float* x, const float* gate_w, const float* gate_b, int32_t* idx_out, float* w_out,
+                          int32_t n_tok, int32_t d, int32_t n_exp, void* stream);
+int32_t amt_glu_expert_fwd(const float* x, const float* w1, const float* b1, const float* wg, const float* bg,
+                           const float* w2, const float* b2, float* out, float* scratch,
+                           int32_t n, int32_t d, int32_t dff, void* stream);
+int32_t amt_moe_combine_fwd(const float* y_rows, const int32_t* slot_pos, const int32_t* idx, const float* wts,
+                            const float* shared, float shared_scale, float* out, int32_t n_tok, int32_t d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

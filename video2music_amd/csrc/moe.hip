@@ -175,6 +175,41 @@ extern "C" int32_t amt_moe_fwd(const float* x, const float* gate_w, const float*
     return 0;
 }
 
+// ---- pieces of the MoE layer for expert-parallel execution (video2music_amd/model/moe.py: route on every rank,
+//      exchange rows with all_to_all, run the local experts, exchange back, combine) ----
+extern "C" int32_t amt_moe_route_fwd(const float* x, const float* gate_w, const float* gate_b, int32_t* idx_out, float* w_out,
+                                     int32_t n_tok, int32_t d, int32_t n_exp, void* stream) {
+    AMT_CHECK_ARG(x && gate_w && idx_out && w_out, "amt_moe_route_fwd: null pointer");
+    AMT_CHECK_ARG(n_tok > 0 && n_exp >= 2 && n_exp <= 64 && d % 4 == 0, "amt_moe_route_fwd: bad shape");
+    hipLaunchKernelGGL(moe_route_kernel, dim3(cdiv(n_tok, 4)), dim3(256), 0, (hipStream_t)stream, x, gate_w, gate_b, n_tok, d, n_exp, idx_out, w_out);
+    AMT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int32_t amt_glu_expert_fwd(const float* x, const float* w1, const float* b1, const float* wg, const float* bg,
+                                      const float* w2, const float* b2, float* out, float* scratch,
+                                      int32_t n, int32_t d, int32_t dff, void* stream) {
+    AMT_CHECK_ARG(x && w1 && wg && w2 && out && scratch, "amt_glu_expert_fwd: null pointer");
+    AMT_CHECK_ARG(n > 0 && d % 32 == 0 && dff % 32 == 0, "amt_glu_expert_fwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    float* G = scratch;                     // [n][dff] gate branch
+    float* Hh = G + (size_t)n * dff;        // [n][dff] (x W1^T + b1) * silu(G)
+    int32_t rc;
+    if ((rc = amt_launch_gemm(gemm_params(x, d, wg, d, G, dff, n, dff, d, bg), s))) return rc;
+    GemmParams u = gemm_params(x, d, w1, d, Hh, dff, n, dff, d, b1);
+    u.silu_mul = G; u.ld_silu = dff;
+    if ((rc = amt_launch_gemm(u, s))) return rc;
+    return amt_launch_gemm(gemm_params(Hh, dff, w2, dff, out, d, n, d, dff, b2), s);
+}
+
+extern "C" int32_t amt_moe_combine_fwd(const float* y_rows, const int32_t* slot_pos, const int32_t* idx, const float* wts,
+                                       const float* shared, float shared_scale, float* out, int32_t n_tok, int32_t d, void* stream) {
+    AMT_CHECK_ARG(y_rows && slot_pos && idx && wts && out && n_tok > 0 && d % 4 == 0, "amt_moe_combine_fwd: bad argument");
+    hipLaunchKernelGGL(moe_combine_kernel, dim3(n_tok), dim3(128), 0, (hipStream_t)stream, y_rows, slot_pos, idx, wts, shared, shared_scale, out, d);
+    AMT_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int32_t amt_gqa_fwd(const float* query, const float* key, const float* value,
                                const float* wq, const float* bq, const float* wk, const float* bk, const float* wv, const float* bv,
                                const float* ln_w, const float* ln_b, const float* wo, const float* bo,

@@ -10,9 +10,60 @@ Training-time behaviour (top-k / temperature schedulers, balancing-bias updates)
 import copy
 
 import torch
+import torch.distributed as dist
 import torch.nn as nn
 
 from .. import _lib
+
+
+def expert_parallel_moe(x, idx, wts, n_experts, run_local_experts, combine, group=None):
+    """Expert-parallel top-2 MoE over ``torch.distributed`` (experts placed per GPU).
+
+    Rank r owns experts ``[r*E/W, (r+1)*E/W)``.  Every rank routes its own tokens (``idx``/``wts`` (n_tok,2)),
+    sends each (token, slot) row to the owner of its expert with ONE ``all_to_all_single`` (rows sorted by
+    expert, so per-rank segments are contiguous), runs its experts on what it received, returns the
+    results with a second ``all_to_all_single`` and combines per token in expert-index order.
+
+    ``run_local_experts(rows, counts_per_local_expert) -> rows`` and ``combine(y_sorted, slot_pos) -> out``
+    are supplied by the caller (HIP kernels in production, the CPU oracle in the gloo test).
+    """
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    assert n_experts % world == 0, "experts must divide evenly over ranks"
+    e_local = n_experts // world
+    n_tok, d = x.shape
+    flat_e = idx.reshape(-1).long()
+    order = torch.argsort(flat_e, stable=True)                     # sorted (token, slot) assignments
+    send_rows = x.index_select(0, order // 2).contiguous()
+    counts = torch.bincount(flat_e, minlength=n_experts)            # rows per expert on this rank
+    send_counts = counts.view(world, e_local).cpu()
+    # 1) sizes: who sends how many rows for which of my experts
+    recv_counts = torch.empty_like(send_counts)
+    cpu_group_ok = dist.get_backend(group) == "gloo"
+    sc_dev = send_counts if cpu_group_ok else send_counts.to(x.device)
+    rc_dev = recv_counts if cpu_group_ok else recv_counts.to(x.device)
+    dist.all_to_all_single(rc_dev, sc_dev, group=group)
+    recv_counts = rc_dev.cpu()
+    in_splits = recv_counts.sum(1).tolist()
+    out_splits = send_counts.sum(1).tolist()
+    # 2) rows to their experts' owners
+    stage = (lambda t: t.cpu()) if (cpu_group_ok and x.is_cuda) else (lambda t: t)
+    recv_rows = torch.empty(sum(in_splits), d, dtype=x.dtype, device="cpu" if (cpu_group_ok and x.is_cuda) else x.device)
+    dist.all_to_all_single(recv_rows, stage(send_rows), output_split_sizes=in_splits, input_split_sizes=out_splits, group=group)
+    recv_rows = recv_rows.to(x.device)
+    # received rows are grouped by source rank, inside a source by local expert: regroup by local expert
+    src_e = torch.repeat_interleave(torch.arange(world * e_local) % e_local, recv_counts.reshape(-1)).to(x.device)
+    by_e = torch.argsort(src_e, stable=True)
+    per_local = recv_counts.sum(0).tolist()
+    y_local = run_local_experts(recv_rows.index_select(0, by_e).contiguous(), per_local)
+    y_recv = torch.empty_like(y_local)
+    y_recv[by_e] = y_local                                          # back to arrival order
+    # 3) results back to the token owners
+    y_sorted = torch.empty(send_rows.shape[0], d, dtype=x.dtype, device="cpu" if (cpu_group_ok and x.is_cuda) else x.device)
+    dist.all_to_all_single(y_sorted, stage(y_recv.contiguous()), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+    y_sorted = y_sorted.to(x.device)
+    slot_pos = torch.empty_like(order)
+    slot_pos[order] = torch.arange(order.numel(), device=order.device)   # row of assignment (token*2+slot) in y_sorted
+    return combine(y_sorted, slot_pos.to(torch.int32).view(n_tok, 2))
 
 
 class GLUExpert(nn.Module):
@@ -30,6 +81,55 @@ def _stack(mods, attr, field):
 
 class _MoEBase(nn.Module):
     shared = False
+    ep_group = None
+    expert_parallel = False
+
+    def enable_expert_parallel(self, group=None):
+        """Config 5: rank r runs experts [r*E/W, (r+1)*E/W); token rows travel by all_to_all (RCCL over xGMI)."""
+        assert dist.is_initialized(), "expert parallelism needs an initialised process group"
+        self.expert_parallel, self.ep_group = True, group
+        return self
+
+    def _run_ep(self, x):
+        L, B, d = x.shape
+        n_tok, n_exp = L * B, self.n_experts
+        dff = self.experts[0].linear1.out_features
+        xf = x.to(torch.float32).contiguous().view(n_tok, d)
+        p, st = _lib.ptr, _lib.stream_ptr
+        idx = torch.empty(n_tok, 2, device=x.device, dtype=torch.int32)
+        wts = torch.empty(n_tok, 2, device=x.device, dtype=torch.float32)
+        gw, gb = self.gate.weight.detach().contiguous(), self.gate.bias.detach().contiguous()
+        _lib.call("amt_moe_route_fwd", p(xf), p(gw), p(gb), p(idx), p(wts), n_tok, d, n_exp, st())
+        world, rank = dist.get_world_size(self.ep_group), dist.get_rank(self.ep_group)
+        e_local = n_exp // world
+
+        def glu(rows, e):
+            m = self.experts[e] if e is not None else self.shared_expert
+            out = torch.empty(rows.shape[0], d, device=rows.device, dtype=torch.float32)
+            if rows.shape[0] == 0:
+                return out
+            scratch = torch.empty(2 * rows.shape[0] * dff, device=rows.device, dtype=torch.float32)
+            t = [v.detach().contiguous() for v in (m.linear1.weight, m.linear1.bias, m.gate.weight, m.gate.bias, m.linear2.weight, m.linear2.bias)]
+            _lib.call("amt_glu_expert_fwd", p(rows), *[p(v) for v in t], p(out), p(scratch), rows.shape[0], d, dff, st())
+            return out
+
+        def run_local(rows, per_local):
+            outs, o = [], 0
+            for j, n in enumerate(per_local):
+                outs.append(glu(rows[o:o + n].contiguous(), rank * e_local + j))
+                o += n
+            return torch.cat(outs) if outs else rows
+
+        def combine(y_sorted, slot_pos):
+            out = torch.empty(n_tok, d, device=x.device, dtype=torch.float32)
+            shared = glu(xf, None) if self.shared else None
+            _lib.call("amt_moe_combine_fwd", p(y_sorted.contiguous()), p(slot_pos.contiguous()), p(idx), p(wts), p(shared),
+                      1.0 / self.n_experts_per_token, p(out), n_tok, d, st())
+            return out
+
+        out = expert_parallel_moe(xf, idx, wts, n_exp, run_local, combine, self.ep_group)
+        self.last_routing = (idx.view(L, B, 2), wts.view(L, B, 2))
+        return out.view(L, B, d)
 
     def _run(self, x):
         if self.training:
@@ -40,6 +140,8 @@ class _MoEBase(nn.Module):
             raise _lib.AmtError("MoE layers run on an MI355X only; video2music_amd has no CPU fallback")
         if self.n_experts_per_token != 2:
             raise NotImplementedError("the gfx950 MoE path is built for top-2 routing (class default)")
+        if self.expert_parallel:
+            return self._run_ep(x)
         L, B, d = x.shape
         n_tok, n_exp = L * B, self.n_experts
         dff = self.experts[0].linear1.out_features
