@@ -1,0 +1,32 @@
+"""Configs 4 and 5 of BASELINE.json on one MI355X: MultiheadGQA(512,8,2) L=2048 and the 8-expert top-2 MoE FFN."""
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from video2music_amd.model.grouped_query_attention import MultiheadGQA
+from video2music_amd.model.moe import GLUExpert, MoELayer, SharedMoELayer
+
+def timeit(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+res = {}
+g = MultiheadGQA(512, 8, 2).cuda().eval()
+for L, B in ((2048, 1), (2048, 4)):
+    x = torch.randn(L, B, 512, device="cuda")
+    dt = timeit(lambda: g(x, x, x, is_causal=True))
+    flops = 2 * L * B * 512 * (2 * 512 + 2 * 128) + 4 * L * L * B * 512 / 2
+    res[f"gqa_L{L}_B{B}"] = {"ms": round(dt * 1e3, 3), "useful_TFLOPs": round(flops / dt / 1e12, 2)}
+for name, layer in (("moe", MoELayer(GLUExpert(512, 1024), 512)), ("shared_moe", SharedMoELayer(GLUExpert(512, 1024), 512))):
+    layer = layer.cuda().eval()
+    for p in layer.parameters():
+        torch.nn.init.normal_(p, std=0.05)
+    for L, B in ((1024, 4), (1024, 32)):
+        x = torch.randn(L, B, 512, device="cuda")
+        dt = timeit(lambda: layer(x))
+        ntok = L * B
+        flops = ntok * (2 * 512 * 8 + 2 * 6 * 512 * 1024 + (6 * 512 * 1024 if name == "shared_moe" else 0))
+        res[f"{name}_L{L}_B{B}"] = {"ms": round(dt * 1e3, 3), "tokens_per_s": round(ntok / dt), "TFLOPs": round(flops / dt / 1e12, 2)}
+print(json.dumps(res))

@@ -43,17 +43,24 @@ __global__ __launch_bounds__(256) void moe_route_kernel(const float* __restrict_
     }
 }
 
-// single workgroup: counts, 128-aligned exclusive scan, stable slot assignment in token order
-__global__ __launch_bounds__(1024) void moe_plan_kernel(const int* __restrict__ idx, int n_tok, int n_exp,
-                                                        int* __restrict__ perm, int* __restrict__ slot_pos,
-                                                        int* __restrict__ tile_group, int Mp) {
-    __shared__ int cnt[64], off[65];
-    const int tid = threadIdx.x;
-    if (tid < 64) cnt[tid] = 0;
+// plan, three small launches (counts -> 128-aligned segment offsets -> placement).  Rows of one expert may land in
+// any order inside its segment: every output row is computed independently, so the values do not depend on it.
+__global__ __launch_bounds__(256) void moe_count_kernel(const int* __restrict__ idx, int n_assign, int* __restrict__ counts) {
+    __shared__ int c[64];
+    if (threadIdx.x < 64) c[threadIdx.x] = 0;
     __syncthreads();
-    for (int i = tid; i < 2 * n_tok; i += 1024) atomicAdd(&cnt[idx[i]], 1);
-    for (int i = tid; i < Mp; i += 1024) perm[i] = -1;
-    for (int i = tid; i < Mp / TILE; i += 1024) tile_group[i] = -1;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_assign) atomicAdd(&c[idx[i]], 1);
+    __syncthreads();
+    if (threadIdx.x < 64 && c[threadIdx.x]) atomicAdd(&counts[threadIdx.x], c[threadIdx.x]);
+}
+
+// counts[0..63] in, offsets[0..64] out (segment starts, multiples of TILE), cursors zeroed, perm = -1, tile_group filled
+__global__ __launch_bounds__(1024) void moe_offsets_kernel(int* __restrict__ counts, int* __restrict__ offsets, int* __restrict__ cursors,
+                                                           int n_exp, int* __restrict__ perm, int* __restrict__ tile_group, int Mp) {
+    __shared__ int off[65], cnt[64];
+    const int tid = threadIdx.x;
+    if (tid < 64) { cnt[tid] = tid < n_exp ? counts[tid] : 0; }
     __syncthreads();
     if (tid == 0) {
         int o = 0;
@@ -61,26 +68,32 @@ __global__ __launch_bounds__(1024) void moe_plan_kernel(const int* __restrict__ 
         off[n_exp] = o;
     }
     __syncthreads();
-    for (int e = 0; e < n_exp; ++e)
-        for (int t = off[e] / TILE + tid; t < (off[e] + cnt[e] + TILE - 1) / TILE; t += 1024) tile_group[t] = e;
-    // deterministic order inside an expert: one wave places the assignments in index order; lane g
-    // carries the running count of expert g in a register (no LDS hazards)
-    if (tid < 64) {
-        int mycnt = 0;
-        for (int base = 0; base < 2 * n_tok; base += 64) {
-            const int i = base + tid;
-            const int e = i < 2 * n_tok ? idx[i] : -1;
-            for (int g = 0; g < n_exp; ++g) {
-                const unsigned long long m = __ballot(e == g);
-                const int start = __shfl(mycnt, g, 64);
-                if (e == g) {
-                    const int pos = off[g] + start + __popcll(m & ((1ull << tid) - 1));
-                    perm[pos] = i >> 1;
-                    slot_pos[i] = pos;
-                }
-                if (tid == g) mycnt += __popcll(m);
-            }
-        }
+    if (tid <= n_exp) offsets[tid] = off[tid];
+    if (tid < 64) { cursors[tid] = 0; counts[tid] = 0; }     // counts are re-zeroed for the next call
+    for (int i = tid; i < Mp; i += 1024) perm[i] = -1;
+    for (int t = tid; t < Mp / TILE; t += 1024) {
+        int g = -1;
+        for (int e = 0; e < n_exp; ++e)
+            if (t * TILE >= off[e] && t * TILE < off[e] + cnt[e]) g = e;
+        tile_group[t] = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void moe_place_kernel(const int* __restrict__ idx, int n_assign, const int* __restrict__ offsets,
+                                                        int* __restrict__ cursors, int* __restrict__ perm, int* __restrict__ slot_pos) {
+    __shared__ int c[64], base[64];
+    if (threadIdx.x < 64) c[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int e = -1, local = 0;
+    if (i < n_assign) { e = idx[i]; local = atomicAdd(&c[e], 1); }
+    __syncthreads();
+    if (threadIdx.x < 64 && c[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursors[threadIdx.x], c[threadIdx.x]);
+    __syncthreads();
+    if (e >= 0) {
+        const int pos = offsets[e] + base[e] + local;
+        perm[pos] = i >> 1;
+        slot_pos[i] = pos;
     }
 }
 
@@ -113,7 +126,7 @@ extern "C" int64_t amt_moe_scratch_floats(int32_t n_tok, int32_t d, int32_t dff,
     const size_t Mp = ((size_t)2 * n_tok + TILE - 1) / TILE * TILE + (size_t)TILE * n_exp;
     // G, H : Mp x dff ; Y : Mp x d ; shared G,H : n_tok x dff ; shared Y : n_tok x d ; ints: perm, slot_pos, tile_group
     return (int64_t)(2 * Mp * dff + Mp * d + 2 * (size_t)n_tok * dff + (size_t)n_tok * d +
-                     align4(Mp) + 3 * align4(2 * (size_t)n_tok) + align4(Mp / TILE + 1) + 64);
+                     align4(Mp) + 3 * align4(2 * (size_t)n_tok) + align4(Mp / TILE + 1) + 256 + 64);
 }
 
 extern "C" int32_t amt_moe_fwd(const float* x, const float* gate_w, const float* gate_b,
@@ -137,12 +150,16 @@ extern "C" int32_t amt_moe_fwd(const float* x, const float* gate_w, const float*
     int* tile_group = slot_pos + align4(2 * (size_t)n_tok);
     int* idx = tile_group + align4(Mp / TILE + 1);
     float* wts = (float*)(idx + align4(2 * (size_t)n_tok));
+    int* plan_ints = (int*)(wts + align4(2 * (size_t)n_tok));     // [0..63] counts, [64..128] offsets, [192..255] cursors
     if (idx_out) idx = idx_out;
     if (w_out) wts = w_out;
+    AMT_HIP(hipMemsetAsync(plan_ints, 0, 64 * sizeof(int), s));
 
     hipLaunchKernelGGL(moe_route_kernel, dim3(cdiv(n_tok, 4)), dim3(256), 0, s, x, gate_w, gate_b, n_tok, d, n_exp, idx, wts);
     AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(moe_plan_kernel, dim3(1), dim3(1024), 0, s, idx, n_tok, n_exp, perm, slot_pos, tile_group, Mp);
+    hipLaunchKernelGGL(moe_count_kernel, dim3(cdiv(2 * n_tok, 256)), dim3(256), 0, s, idx, 2 * n_tok, plan_ints);
+    hipLaunchKernelGGL(moe_offsets_kernel, dim3(1), dim3(1024), 0, s, plan_ints, plan_ints + 64, plan_ints + 192, n_exp, perm, tile_group, Mp);
+    hipLaunchKernelGGL(moe_place_kernel, dim3(cdiv(2 * n_tok, 256)), dim3(256), 0, s, idx, 2 * n_tok, plan_ints + 64, plan_ints + 192, perm, slot_pos);
     AMT_LAUNCH_CHECK();
     int32_t rc;
     // gate branch: G = x_e . Wg[e]^T + bg[e]

@@ -131,6 +131,17 @@ class _MoEBase(nn.Module):
         self.last_routing = (idx.view(L, B, 2), wts.view(L, B, 2))
         return out.view(L, B, d)
 
+    def _stacked_expert_weights(self):
+        """(n_exp, ...) contiguous copies of the experts' tensors for the grouped GEMMs, rebuilt only when a
+        parameter changed (the library takes one base pointer + a per-expert stride)."""
+        sig = tuple((p.data_ptr(), p._version) for e in self.experts for p in e.parameters())
+        if getattr(self, "_stack_sig", None) != sig:
+            self._stack = (_stack(self.experts, "linear1", "weight"), _stack(self.experts, "linear1", "bias"),
+                           _stack(self.experts, "gate", "weight"), _stack(self.experts, "gate", "bias"),
+                           _stack(self.experts, "linear2", "weight"), _stack(self.experts, "linear2", "bias"))
+            self._stack_sig = sig
+        return self._stack
+
     def _run(self, x):
         if self.training:
             raise NotImplementedError("MoE training (schedulers, balancing updates) is outside the hot path")
@@ -147,9 +158,7 @@ class _MoEBase(nn.Module):
         dff = self.experts[0].linear1.out_features
         xf = x.to(torch.float32).contiguous()
         p = _lib.ptr
-        w1, b1 = _stack(self.experts, "linear1", "weight"), _stack(self.experts, "linear1", "bias")
-        wg, bg = _stack(self.experts, "gate", "weight"), _stack(self.experts, "gate", "bias")
-        w2, b2 = _stack(self.experts, "linear2", "weight"), _stack(self.experts, "linear2", "bias")
+        w1, b1, wg, bg, w2, b2 = self._stacked_expert_weights()
         sh = [None] * 6
         if self.shared:
             e = self.shared_expert
