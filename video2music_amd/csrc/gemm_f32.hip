@@ -126,17 +126,73 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         }
     }
 
+    // ---- epilogue ----
     // C/D layout of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const bool vec_ok = (p.N % 4 == 0) && (p.head_split || p.ldc % 4 == 0) && (!p.resid || p.ldr % 4 == 0) &&
+                        (!p.silu_mul || p.ld_silu % 4 == 0);
+    if (!vec_ok) {      // odd widths (Wout: N = 159): element-wise stores
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    int row = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                    int col = n0 + wc * 64 + j * 32 + fr;
+                    store_out(p, row, col, acc[i][j][e]);
+                }
+        return;
+    }
+    // transpose the 128x128 tile through LDS (the operand buffers are free now) so that every lane owns 4
+    // consecutive columns: bias / residual / gate loads and the output stores become 16-byte and row-contiguous
+    constexpr int CLD = BN + 4;
+    float* ct = &lds[0][0][0];                       // 128 x 132 floats = 67.6 KB <= the 73.7 KB of operand buffers
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                int row = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                int col = n0 + wc * 64 + j * 32 + fr;
-                store_out(p, row, col, acc[i][j][e]);
+                const int r = wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                ct[r * CLD + wc * 64 + j * 32 + fr] = acc[i][j][e];
             }
+    __syncthreads();
+    const int c4 = (tid & 31) * 4, col = n0 + c4;
+    if (col >= p.N) return;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bias4 = ld4(p.bias + col);
+    const float sc[4] = {col + 0 < p.scale_cols ? p.scale : 1.f, col + 1 < p.scale_cols ? p.scale : 1.f,
+                         col + 2 < p.scale_cols ? p.scale : 1.f, col + 3 < p.scale_cols ? p.scale : 1.f};
+    for (int r = tid >> 5; r < BM; r += 8) {
+        const int row = m0 + r;
+        if (row >= p.M) break;
+        float4 v = ld4(&ct[r * CLD + c4]);
+        v.x = (v.x + bias4.x) * sc[0]; v.y = (v.y + bias4.y) * sc[1]; v.z = (v.z + bias4.z) * sc[2]; v.w = (v.w + bias4.w) * sc[3];
+        if (p.silu_mul) {
+            const float4 g = ld4(p.silu_mul + (size_t)row * p.ld_silu + col);
+            v.x *= g.x / (1.0f + __expf(-g.x)); v.y *= g.y / (1.0f + __expf(-g.y));
+            v.z *= g.z / (1.0f + __expf(-g.z)); v.w *= g.w / (1.0f + __expf(-g.w));
+        }
+        if (p.rowadd) {
+            const float4 a = ld4(p.rowadd + (size_t)(row % p.rowadd_period) * p.N + col);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        if (p.resid) {
+            const float4 a = ld4(p.resid + (size_t)row * p.ldr + col);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (p.head_split == 0) {
+            st4(p.C + (size_t)row * p.ldc + col, v);
+        } else {
+            // row = b*seq + s, col = part*d + h*hd + c  ->  out[part][b][h][s][c]; hd % 4 == 0 keeps the 4 columns in one head
+            const int b = row / p.hs_seq, ss = row - b * p.hs_seq;
+            const int part = col / p.hs_d, cc = col - part * p.hs_d;
+            const int h = cc / p.hs_hd, c = cc - h * p.hs_hd;
+            st4(p.C + (size_t)part * p.hs_part_stride + (((size_t)b * p.hs_heads + h) * p.hs_seq_cap + ss) * p.hs_hd + c, v);
+        }
+    }
 }
 
 }  // namespace
