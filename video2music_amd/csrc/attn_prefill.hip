@@ -12,10 +12,10 @@
 // B-operand layout of the second product
 //   O^T[d][query] += V^T . P^T    A = V^T read from the LDS V tile, B = P^T accumulator registers.
 //
-// Relative positions (bias[i][j] = q_i . Er[er_len-1-(i-j)], j <= i): per tile the
-// 63 distinct distances i-j form a band; R^T[m][query] = Er_band . Q^T is two more MFMA tiles
-// (A = Er rows straight from L2), written to a per-wave LDS scratch and read back along the skew
-// diagonal m = (i - j) - rel_min.
+// Relative positions (bias[i][j] = q_i . Er[er_len-1-(i-j)], j <= i): the distances of a
+// 32x32 tile lie in two aligned chunks of 32; R^T[m][query] = Er_chunk . Q^T is one MFMA tile per chunk
+// (A = Er rows straight from L2).  Consecutive key tiles share a chunk, so each tile computes ONE new
+// chunk into a 2-slot per-wave LDS ring and reads the bias back along the skew diagonal.
 #include "amt_common.h"
 #include "kernels.h"
 
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     constexpr int LD = HD + 4;
     constexpr int NS = HD / 8;           // ds_read_b128 k-groups per operand row
     constexpr int ND = HD / 32;          // 32-wide d tiles of O^T
-    constexpr int SCR = 32 * 65 > 32 * (HD + 1) ? 32 * 65 : 32 * (HD + 1);
+    constexpr int SCR = 2 * 32 * 33 > 32 * (HD + 1) ? 2 * 32 * 33 : 32 * (HD + 1);   // two 32x33 distance chunks / the O transpose
     __shared__ __attribute__((aligned(16))) float Ks[KT * LD];
     __shared__ __attribute__((aligned(16))) float Vs[KT * LD];
     __shared__ __attribute__((aligned(16))) float scr_all[4 * SCR];
@@ -113,13 +113,15 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
             sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * s + 3], sacc, 0, 0, 0);
         }
 
-        // ---- relative-position band: R^T[m][query] = Er[er_len-1-(rel_min+m)] . q ----
+        // ---- relative-position term.  With D = i0 - j0 = 32k the distances of this tile, D-31 .. D+31, lie in the
+        //      aligned chunks k-1 and k of 32 distances each; chunk c holds R^T[m][query] = Er[er_len-1-(32c+m)] . q.
+        //      Tiles are visited with k descending, so chunk k was produced by the previous tile (as its k-1) and
+        //      only chunk k-1 is new: one extra MFMA tile per key tile, kept in a 2-slot per-wave LDS ring. ----
         if (RPR) {
-            const int rel_min = i0 - j0 - 31;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                int row = p.er_len - 1 - (rel_min + mt * 32 + li);
-                row = max(0, min(p.er_len - 1, row));      // out-of-band rows belong to masked pairs
+            const int k = (i0 - j0) / 32;
+            auto chunk = [&](int c) {
+                int row = p.er_len - 1 - (32 * c + li);
+                row = max(0, min(p.er_len - 1, row));      // out-of-range rows belong to masked pairs
                 const float* ep = p.Er + (size_t)row * HD + 4 * lh;
                 float4 ef[NS];
 #pragma unroll
@@ -134,16 +136,18 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
                     racc = __builtin_amdgcn_mfma_f32_32x32x2f32(ef[s].z, qreg[4 * s + 2], racc, 0, 0, 0);
                     racc = __builtin_amdgcn_mfma_f32_32x32x2f32(ef[s].w, qreg[4 * s + 3], racc, 0, 0, 0);
                 }
+                float* slot = scr + (c & 1) * (32 * 33);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    scr[li * 65 + m] = racc[e];
-                }
-            }
+                for (int e = 0; e < 16; ++e) slot[li * 33 + (e & 3) + 8 * (e >> 2) + 4 * lh] = racc[e];
+            };
+            if (kt == 0) chunk(k);                          // first tile of this wave's row block: both chunks are new
+            if (k >= 1) chunk(k - 1);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int krow = (e & 3) + 8 * (e >> 2) + 4 * lh;
-                sacc[e] += scr[li * 65 + (li - krow + 31)];
+                const int dlt = li - krow;                  // distance - D
+                const int c = dlt >= 0 ? k : k - 1;
+                sacc[e] += scr[(c & 1) * (32 * 33) + li * 33 + (dlt & 31)];
             }
         }
 
