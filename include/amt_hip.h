@@ -137,6 +137,19 @@ int32_t amt_rpr_attn_fwd(const float* q, const float* k, const float* v, const f
  * scaled, k,v (B,Lk,H*hd); no mask (causal=0) or causal. */
 int32_t amt_cross_attn_fwd(const float* q, const float* k, const float* v, float* o,
                            int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd, int32_t causal, void* stream);
+/* General strided form of the same kernel (used by the V2 stack and MultiheadGQA): tensor[b][h][l][c] lives at
+ * base + b*bs + h*hs + l*ls + c with strides = {q_bs,q_hs,q_ls, k_bs,k_hs,k_ls, v_bs,v_hs,v_ls, o_bs,o_hs,o_ls} in
+ * elements; q_scale multiplies q (torch MHA: hd^-0.5; 0 = 1); query head h reads kv head h / kv_group. */
+int32_t amt_attn_fwd(const float* q, const float* k, const float* v, float* o, const int64_t* strides,
+                     int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd, int32_t causal, int32_t kv_group,
+                     float q_scale, void* stream);
+/* Input stage pieces of forward (video_music_transformer.py:984-1030): out[row][0:ld_out] = [sem | scene | motion |
+ * emotion | 0-pad]; xf[b*L+l] = PR[root] + PA[attr] + key[b]*wkey + bias + pe[l] with PR = E_root.Wc[:, :d]^T etc. */
+int32_t amt_concat_features_fwd(const float* sem, int32_t sem_dim, const float* scene, const float* motion, int32_t motion_dim,
+                                const float* emotion, int32_t emo_dim, float* out, int32_t rows, int32_t ld_out, void* stream);
+int32_t amt_chord_embed_fwd(const int64_t* root, const int64_t* attr, const float* key, const float* PR, const float* PA,
+                            const float* wkey, const float* bias, const float* pe, float* out,
+                            int32_t B, int32_t L, int32_t d, void* stream);
 /* Decode-step forms: q (B,H*hd) for the token at position pos (host value), K/V caches
  * (B,H,cap,hd); keys 0..pos.  Er may be null (cross-attention: pass pos = S-1). */
 int32_t amt_attn_decode_fwd(const float* q, const float* kcache, const float* vcache, const float* Er, float* o,

@@ -213,7 +213,8 @@ def root_attr_of(tok):
 
 
 def generate(sd, H, sem, key, scene_off, motion, emotion, primer, primer_root, primer_attr,
-             target_seq_length=300, beam=0, max_conseq_N=0, max_conseq_chord=2, margins=None):
+             target_seq_length=300, beam=0, max_conseq_N=0, max_conseq_chord=2, margins=None, forward_fn=None,
+             temperature=1.0):
     """VideoMusicTransformer.generate (model/video_music_transformer.py:1046-1132), one clip,
     full re-forward every step exactly like the reference (no KV cache, encoder re-run).
 
@@ -232,8 +233,8 @@ def generate(sd, H, sem, key, scene_off, motion, emotion, primer, primer_root, p
     gen_attr[0, :P] = primer_attr
     cur = P
     while cur < T:
-        logits = forward(sd, H, gen_root[:, :cur], gen_attr[:, :cur], sem, key, scene_off, motion, emotion)
-        y = torch.softmax(logits, dim=-1)[..., :CHORD_END]
+        logits = (forward_fn or forward)(sd, H, gen_root[:, :cur], gen_attr[:, :cur], sem, key, scene_off, motion, emotion)
+        y = torch.softmax(logits / temperature, dim=-1)[..., :CHORD_END]
         probs = y[:, cur - 1, :].clone()
         if beam > 0:
             tok = int(torch.topk(probs.flatten(), 1)[1][0]) % CHORD_SIZE
@@ -261,6 +262,75 @@ def generate(sd, H, sem, key, scene_off, motion, emotion, primer, primer_root, p
             margins.append(float(top2[0] - top2[1]))
         cur += 1
     return gen[:, :cur]
+
+
+# ----------------------------------------------------------------------------------------------
+# VideoMusicTransformer_V2, version '2.2' (model/video_music_transformer.py:316-609)
+# ----------------------------------------------------------------------------------------------
+def v2_attention(xq, xkv, sd, prefix, H, cache, causal):
+    """CustomMultiheadAttention with RoPE (model/custom_transformer.py:864-1218): packed in-proj, RoPE on q and k
+    through the raw (H, L, B, hd) view of the seq-first (L, B, E) buffers (:1041-1053), q * hd^-0.5, softmax, out-proj.
+    Inputs/outputs are seq-first (L, B, E) because the view above depends on that memory order."""
+    L, B, E = xq.shape
+    S = xkv.shape[0]
+    hd = E // H
+    W, b = sd[prefix + "in_proj_weight"], sd[prefix + "in_proj_bias"]
+    q = linear(xq, W[:E], b[:E]).contiguous()
+    k = linear(xkv, W[E:2 * E], b[E:2 * E]).contiguous()
+    v = linear(xkv, W[2 * E:], b[2 * E:]).contiguous()
+    q = rope(q.view(H, L, B, hd), cache).reshape(L, B, E)
+    k = rope(k.view(H, S, B, hd), cache).reshape(S, B, E)
+    qh = q.reshape(L, B * H, hd).transpose(0, 1) * math.sqrt(1.0 / float(hd))
+    kh = k.reshape(S, B * H, hd).transpose(0, 1)
+    vh = v.reshape(S, B * H, hd).transpose(0, 1)
+    s = qh @ kh.transpose(-1, -2)
+    if causal:
+        s = s + torch.triu(torch.full((L, S), float("-inf"), dtype=s.dtype), diagonal=1)
+    o = torch.softmax(s, dim=-1) @ vh                                  # (B*H, L, hd)
+    o = o.transpose(0, 1).contiguous().view(L * B, E)
+    return linear(o, sd[prefix + "out_proj.weight"], sd[prefix + "out_proj.bias"]).view(L, B, E)
+
+
+def v2_ff(x, sd, prefix):
+    """GLUExpert for the three shallow layers, SharedMoELayer(6 experts, top-2) for the deep ones
+    (model/video_music_transformer.py:384-416)."""
+    if prefix + "linear1.weight" in sd:
+        return glu_expert(x, sd, prefix)
+    sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    n_exp = sub["gate.weight"].shape[0]
+    return moe_forward(x, sub, n_exp, k=2, shared=True)
+
+
+def forward_v2(sd, H, x_root, x_attr, sem, key, scene_off, motion, emotion, max_seq_video=300):
+    """VideoMusicTransformer_V2.forward, version '2.2', chord_embed=False (:427-516): no additive positional
+    encoding, RoPE inside every attention, post-norm layers (custom_transformer.py:1228-1240, 1260-1276)."""
+    d = sd["Wout.weight"].shape[1]
+    cache = rope_cache(d, max_seq_video).to(sd["Wout.weight"].dtype)
+    x = sd["embedding_root.weight"][x_root] + sd["embedding_attr.weight"][x_attr]
+    B, L, _ = x.shape
+    kk = key.to(x.dtype).reshape(-1)
+    if kk.numel() == 1:
+        kk = kk.expand(B)
+    x = linear(torch.cat([x, kk.view(B, 1, 1).expand(B, L, 1)], dim=-1), sd["Linear_chord.weight"], sd["Linear_chord.bias"])
+    vf = sem.to(x.dtype)
+    vf = torch.cat([vf, scene_off.unsqueeze(-1).to(x.dtype)], dim=-1)
+    vf = torch.cat([vf, motion.unsqueeze(-1).to(x.dtype) if motion.dim() == 2 else motion.to(x.dtype)], dim=-1)
+    vf = torch.cat([vf, emotion.to(x.dtype)], dim=-1)
+    vf = linear(vf, sd["Linear_vis.weight"], sd["Linear_vis.bias"])
+    xf, src = x.permute(1, 0, 2).contiguous(), vf.permute(1, 0, 2).contiguous()     # seq-first
+    for i in range(n_layers_of(sd, "encoder")):
+        p = f"transformer.encoder.layers.{i}."
+        src = layer_norm(src + v2_attention(src, src, sd, p + "self_attn.", H, cache, False), sd[p + "norm1.weight"], sd[p + "norm1.bias"])
+        src = layer_norm(src + v2_ff(src, sd, p + "ff."), sd[p + "norm2.weight"], sd[p + "norm2.bias"])
+    memory = layer_norm(src, sd["transformer.encoder.norm.weight"], sd["transformer.encoder.norm.bias"])
+    t = xf
+    for i in range(n_layers_of(sd, "decoder")):
+        p = f"transformer.decoder.layers.{i}."
+        t = layer_norm(t + v2_attention(t, t, sd, p + "self_attn.", H, cache, True), sd[p + "norm1.weight"], sd[p + "norm1.bias"])
+        t = layer_norm(t + v2_attention(t, memory, sd, p + "cross_attn.", H, cache, False), sd[p + "norm2.weight"], sd[p + "norm2.bias"])
+        t = layer_norm(t + v2_ff(t, sd, p + "ff."), sd[p + "norm3.weight"], sd[p + "norm3.bias"])
+    t = layer_norm(t, sd["transformer.decoder.norm.weight"], sd["transformer.decoder.norm.bias"])
+    return linear(t.permute(1, 0, 2), sd["Wout.weight"], sd["Wout.bias"])
 
 
 # ----------------------------------------------------------------------------------------------

@@ -191,6 +191,41 @@ def main():
               "min margin", min(margins[:63]))
     np.savez_compressed(os.path.join(OUT, "g_gen_cfg1.npz"), **gen)
 
+    # ---------------- V2 '2.2' (the reference's default music_gen_version): forward + G1/G2 ----------------
+    v2 = {}
+    cfg2 = dict(version_name="2.2", n_layers=6, num_heads=4, d_model=128, dim_feedforward=256, max_sequence_chord=300,
+                total_vf_dim=synthetic.total_vf_dim(1))
+    m2 = ref.vmt.VideoMusicTransformer_V2(**cfg2).eval()
+    load_synthetic(m2, seed=0)
+    rs = np.random.RandomState(13)
+    for B in (1, 2):
+        for L in (1, 12):
+            rootv = rs.randint(0, 13, size=(B, L)).astype(np.int64)
+            attrv = rs.randint(0, 14, size=(B, L)).astype(np.int64)
+            sl = slice(0, B)
+            y = m2(torch.zeros_like(t(rootv)), t(rootv), t(attrv), t(feats["semantic"][sl]), t(key[sl]),
+                   t(feats["scene_offset"][sl]), t(feats["motion"][sl]), t(feats["emotion"][sl]))
+            v2[f"root_B{B}_L{L}"], v2[f"attr_B{B}_L{L}"], v2[f"logits_B{B}_L{L}"] = rootv, attrv, y.numpy()
+    kw = dict(feature_semantic_list=t(feats["semantic"][:1]), feature_key=t(key[0]), feature_scene_offset=t(feats["scene_offset"][:1]),
+              feature_motion=t(feats["motion"][:1]), feature_emotion=t(feats["emotion"][:1]),
+              primer=torch.tensor([1]), primer_root=torch.tensor([1]), primer_attr=torch.tensor([0]), target_seq_length=24)
+    v2["g1"] = m2.generate(beam=1, beam_chance=1.0, **kw).numpy()
+    vm = []
+
+    def argmax_sample_v2(self, sample_shape=torch.Size()):
+        top2 = torch.topk(self.probs.flatten(), 2)[0]
+        vm.append(float(top2[0] - top2[1]))
+        return self.probs.argmax(-1)
+
+    Categorical.sample = argmax_sample_v2
+    try:
+        v2["g2"] = m2.generate(beam=0, **kw).numpy()
+    finally:
+        Categorical.sample = orig_sample
+    v2["g2_margins"] = np.array(vm, dtype=np.float64)
+    print("V2 G1 unique", len(set(v2["g1"].flatten().tolist())), "G2 unique", len(set(v2["g2"].flatten().tolist())), "min margin", min(vm))
+    np.savez_compressed(os.path.join(OUT, "g_v2_cfg1.npz"), **v2)
+
     # ---------------- G-gqa ----------------
     gq = {}
     m = ref.gqa.MultiheadGQA(256, 8, 2).eval()        # head_dim 32, 4 query heads per kv head

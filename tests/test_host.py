@@ -55,6 +55,15 @@ def test_state_dict_matches_reference_key_set(cfg):
     assert mask[0, 1] == float("-inf") and mask[1, 0] == 0
 
 
+def test_v2_state_dict_matches_reference_key_set():
+    from tests.helpers import CFG_V2, v2_named_shapes
+    from video2music_amd.model.video_music_transformer import VideoMusicTransformer_V2
+    m = VideoMusicTransformer_V2(**CFG_V2)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == dict(v2_named_shapes(**CFG_V2))
+    with pytest.raises(NotImplementedError):
+        VideoMusicTransformer_V2(version_name="2.0", total_vf_dim=1287)
+
+
 def test_unsupported_constructor_options_raise():
     with pytest.raises(NotImplementedError):
         VideoMusicTransformer(total_vf_dim=1287, rpr=False)
@@ -83,6 +92,7 @@ def test_generate_flags_and_feature_widths():
     args = parse_generate_args([])[0]
     assert (args.target_seq_length_chord, args.beam, args.n_layers, args.num_heads, args.d_model, args.dim_feedforward) == (300, 0, 6, 8, 512, 1024)
     assert (args.max_sequence_video, args.max_sequence_chord, args.motion_type, args.rpr) == (300, 300, 1, True)
+    assert args.music_gen_version == "2.2"                  # reference default (argument_generate_funcs.py:82)
     from video2music_amd.generate import total_vf_dim_of, default_primer
     assert total_vf_dim_of(args) == 1287 == synthetic.total_vf_dim(1)
     args.motion_type = 0

@@ -128,3 +128,30 @@ def test_rms_rope(golden):
         assert np.abs(y.numpy() - g[f"rope_y_B{B}"]).max() < 1e-6
     y = O.rope(torch.from_numpy(g["rope_hd_x"]), O.rope_cache(32, 64))
     assert np.abs(y.numpy() - g["rope_hd_y"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("B,L", [(1, 1), (1, 12), (2, 1), (2, 12)])
+def test_v2_forward_logits(golden, B, L):
+    """VideoMusicTransformer_V2 '2.2' (row f1): RoPE attention, GLU / shared-MoE feed-forwards."""
+    from tests.helpers import CFG_V2, synthetic_sd_v2
+    g = golden("g_v2_cfg1.npz")
+    key = golden("g_fwd_cfg1.npz")["key"]
+    sd = synthetic_sd_v2(CFG_V2)
+    f = feats_t(synthetic.synthetic_features(3, seed=1234), slice(0, B), key=key)
+    logits = O.forward_v2(sd, 4, torch.from_numpy(g[f"root_B{B}_L{L}"]), torch.from_numpy(g[f"attr_B{B}_L{L}"]),
+                          f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"])
+    assert np.abs(logits.numpy() - g[f"logits_B{B}_L{L}"]).max() < 5e-5      # 12 layers + MoE, logits of magnitude ~10
+
+
+def test_v2_generate(golden):
+    from tests.helpers import CFG_V2, synthetic_sd_v2
+    g = golden("g_v2_cfg1.npz")
+    key = golden("g_fwd_cfg1.npz")["key"]
+    sd = synthetic_sd_v2(CFG_V2)
+    f = feats_t(synthetic.synthetic_features(3, seed=1234), slice(0, 1), key=key)
+    args = (sd, 4, f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], torch.tensor([1]), torch.tensor([1]), torch.tensor([0]))
+    assert np.array_equal(O.generate(*args, target_seq_length=24, beam=1, forward_fn=O.forward_v2).numpy(), g["g1"])
+    margins = []
+    g2 = O.generate(*args, target_seq_length=24, beam=0, forward_fn=O.forward_v2, margins=margins)
+    assert np.array_equal(g2.numpy(), g["g2"])
+    assert np.abs(np.array(margins) - g["g2_margins"]).max() < 1e-4

@@ -50,6 +50,9 @@ SIGNATURES = {
     "amt_rope_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "amt_rpr_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "amt_cross_attn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "amt_attn_fwd": [_P, _P, _P, _P, C.POINTER(C.c_int64), _I, _I, _I, _I, _I, _I, _I, _F, _P],
+    "amt_concat_features_fwd": [_P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _P],
+    "amt_chord_embed_fwd": [_P] * 9 + [_I, _I, _I, _P],
     "amt_attn_decode_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "amt_decode_linear_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "amt_gqa_fwd": [_P] * 15 + [_I] * 7 + [_F, _P],

@@ -793,6 +793,33 @@ extern "C" int32_t amt_cross_attn_fwd(const float* q, const float* k, const floa
     return amt_launch_attn_prefill(a, (hipStream_t)stream);
 }
 
+extern "C" int32_t amt_attn_fwd(const float* q, const float* k, const float* v, float* o, const int64_t* strides,
+                                int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd, int32_t causal, int32_t kv_group,
+                                float q_scale, void* stream) {
+    AMT_CHECK_ARG(q && k && v && o && strides, "amt_attn_fwd: null pointer");
+    AttnParams a{};
+    a.q = q; a.k = k; a.v = v; a.o = o;
+    a.q_bs = strides[0]; a.q_hs = strides[1]; a.q_ls = strides[2];
+    a.k_bs = strides[3]; a.k_hs = strides[4]; a.k_ls = strides[5];
+    a.v_bs = strides[6]; a.v_hs = strides[7]; a.v_ls = strides[8];
+    a.o_bs = strides[9]; a.o_hs = strides[10]; a.o_ls = strides[11];
+    a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.hd = hd; a.causal = causal; a.kv_group = kv_group > 0 ? kv_group : 1; a.q_scale = q_scale;
+    return amt_launch_attn_prefill(a, (hipStream_t)stream);
+}
+
+extern "C" int32_t amt_concat_features_fwd(const float* sem, int32_t sem_dim, const float* scene, const float* motion, int32_t motion_dim,
+                                           const float* emotion, int32_t emo_dim, float* out, int32_t rows, int32_t ld_out, void* stream) {
+    AMT_CHECK_ARG(sem && scene && motion && emotion && out && rows > 0, "amt_concat_features_fwd: bad argument");
+    return amt_launch_concat_features(sem, sem_dim, scene, motion, motion_dim, emotion, emo_dim, out, rows, ld_out, (hipStream_t)stream);
+}
+
+extern "C" int32_t amt_chord_embed_fwd(const int64_t* root, const int64_t* attr, const float* key, const float* PR, const float* PA,
+                                       const float* wkey, const float* bias, const float* pe, float* out,
+                                       int32_t B, int32_t L, int32_t d, void* stream) {
+    AMT_CHECK_ARG(root && attr && key && PR && PA && wkey && bias && pe && out && B > 0 && L > 0, "amt_chord_embed_fwd: bad argument");
+    return amt_launch_chord_embed(root, attr, key, PR, PA, wkey, bias, pe, out, B, L, d, (hipStream_t)stream);
+}
+
 extern "C" int32_t amt_attn_decode_fwd(const float* q, const float* kcache, const float* vcache, const float* Er, float* o,
                                        int32_t B, int32_t H, int32_t hd, int32_t cap, int32_t pos, int32_t er_len, void* stream) {
     AMT_CHECK_ARG(q && kcache && vcache && o, "amt_attn_decode_fwd: null pointer");

@@ -46,12 +46,13 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     const float* kp = p.k + (size_t)b * p.k_bs + (size_t)hk * p.k_hs;
     const float* vp = p.v + (size_t)b * p.v_bs + (size_t)hk * p.v_hs;
 
-    // Q^T fragments: qreg[4s+e] = Q[iq][8s + 4*lh + e]
+    // Q^T fragments: qreg[4s+e] = Q[iq][8s + 4*lh + e] (* q_scale)
+    const float qs = p.q_scale == 0.f ? 1.f : p.q_scale;
     float qreg[HD / 2];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         float4 t = (iq < p.Lq) ? ld4(qp + (size_t)iq * p.q_ls + 8 * s + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
-        qreg[4 * s + 0] = t.x; qreg[4 * s + 1] = t.y; qreg[4 * s + 2] = t.z; qreg[4 * s + 3] = t.w;
+        qreg[4 * s + 0] = t.x * qs; qreg[4 * s + 1] = t.y * qs; qreg[4 * s + 2] = t.z * qs; qreg[4 * s + 3] = t.w * qs;
     }
 
     f32x16 oacc[ND];

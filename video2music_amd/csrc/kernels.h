@@ -58,6 +58,7 @@ struct AttnParams {
     const float* Er; int er_len;   // relative position table [er_len][hd] or null
     int kv_group;               // query head h uses kv head h / kv_group (GQA); 1 for MHA
     float mask_value;           // -inf (additive mask semantics) or finfo.min (masked_fill semantics)
+    float q_scale;              // multiplies Q on load (0 = unset = 1): torch MHA scales q by hd^-0.5 after the in-projection
 };
 int32_t amt_launch_attn_prefill(const AttnParams& p, hipStream_t stream);
 

@@ -18,7 +18,7 @@ import torch
 
 from . import dist as vdist
 from . import synthetic
-from .model.video_music_transformer import VideoMusicTransformer
+from .model.video_music_transformer import VideoMusicTransformer, VideoMusicTransformer_V2
 from .utilities import constants as C
 from .utilities.argument_generate_funcs import parse_generate_args
 from .utilities.device import get_device
@@ -43,18 +43,23 @@ def default_primer(feature_key):
 
 def main(argv=None):
     args = parse_generate_args(argv)[0]
-    if args.music_gen_version is not None:
-        raise SystemExit("this build implements the base AMT (music_gen_version=None); V1/V2/V3 are SURVEY.md §8 row f1")
+    if args.music_gen_version in ("None", "none", ""):
+        args.music_gen_version = None
+    if args.music_gen_version not in (None, "2.2"):
+        raise SystemExit("built: music_gen_version None (base AMT) and '2.2' (VideoMusicTransformer_V2); the other V1/V2/V3 variants are SURVEY.md §8 row f1")
     if args.force_cpu:
         raise SystemExit("--force_cpu: video2music_amd has no CPU path (the CPU oracle lives in oracle/ for tests only)")
     rank, world, local = vdist.init()
     device = get_device()
     if device.type != "cuda":
         raise SystemExit("no GPU visible: video2music_amd runs on MI355X only")
-    model = VideoMusicTransformer(n_layers=args.n_layers, num_heads=args.num_heads, d_model=args.d_model,
-                                  dim_feedforward=args.dim_feedforward, max_sequence_midi=args.max_sequence_midi,
-                                  max_sequence_video=args.max_sequence_video, max_sequence_chord=args.max_sequence_chord,
-                                  total_vf_dim=total_vf_dim_of(args), rpr=args.rpr)
+    common = dict(n_layers=args.n_layers, num_heads=args.num_heads, d_model=args.d_model, dim_feedforward=args.dim_feedforward,
+                  max_sequence_midi=args.max_sequence_midi, max_sequence_video=args.max_sequence_video,
+                  max_sequence_chord=args.max_sequence_chord, total_vf_dim=total_vf_dim_of(args))
+    if args.music_gen_version is None:                 # generate.py:209-216
+        model = VideoMusicTransformer(rpr=args.rpr, **common)
+    else:                                              # generate.py:225-230
+        model = VideoMusicTransformer_V2(version_name=args.music_gen_version, rms_norm=args.rms_norm, **common)
     if args.synthetic:
         shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
         sd = {k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=0).items()}
@@ -72,10 +77,20 @@ def main(argv=None):
         if args.beam > 1:
             assert False, "No Beam sampling method implemented yet..."     # generate.py:347-349
         print("RAND DIST" if args.beam == 0 else "BEAM: 1")
-        toks = model.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"],
-                                    prim[:, 0:1], prim[:, 1:2], prim[:, 2:3],
-                                    target_seq_length=args.target_seq_length_chord, beam=args.beam,
-                                    max_conseq_N=max_conseq_N, max_conseq_chord=max_conseq_chord, sampler=args.sampler)
+        if args.music_gen_version is None:
+            toks = model.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"],
+                                        prim[:, 0:1], prim[:, 1:2], prim[:, 2:3],
+                                        target_seq_length=args.target_seq_length_chord, beam=args.beam,
+                                        max_conseq_N=max_conseq_N, max_conseq_chord=max_conseq_chord, sampler=args.sampler)
+        else:                                          # V2 generates one clip at a time like the reference
+            rows = []
+            for i in range(hi - lo):
+                sl = slice(i, i + 1)
+                rows.append(model.generate(f["semantic"][sl], f["key"][i], f["scene_offset"][sl], f["motion"][sl], f["emotion"][sl],
+                                           prim[i, 0:1], prim[i, 1:2], prim[i, 2:3], target_seq_length=args.target_seq_length_chord,
+                                           beam=args.beam, max_conseq_N=max_conseq_N, max_conseq_chord=max_conseq_chord,
+                                           sampler=args.sampler))
+            toks = torch.cat(rows) if rows else torch.empty(0, args.target_seq_length_chord, dtype=torch.long, device=device)
         toks = vdist.all_gather_sequences(toks, args.n_clips)
     if rank == 0:
         os.makedirs(args.output_dir, exist_ok=True)

@@ -367,3 +367,201 @@ class VideoMusicTransformer(nn.Module):
             if return_logits:
                 logits[:, sl] = lg
         return (tokens, logits) if return_logits else tokens
+
+
+# ==================================================================================================
+# VideoMusicTransformer_V2, version '2.2' (the reference's default music_gen_version)
+# ==================================================================================================
+class _DecoderLayerV2(nn.Module):
+    """Keys of custom_transformer.TransformerDecoderLayer (model/custom_transformer.py:1250-1292)."""
+
+    def __init__(self, d_model, head_dim, ff, cross):
+        super().__init__()
+        self.self_attn = _AttnParams(d_model, head_dim)
+        if cross:
+            self.cross_attn = _AttnParams(d_model, head_dim)
+        self.ff = ff
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        if cross:
+            self.norm3 = nn.LayerNorm(d_model)
+
+
+class _TransformerParamsV2(nn.Module):
+    def __init__(self, d_model, nhead, n_layers, d_ff, dropout, n_experts, balancing):
+        super().__init__()
+        from .moe import GLUExpert, SharedMoELayer
+        hd = d_model // nhead
+
+        def ff(i):
+            if i < 3:                                            # rate = 3 shallow layers (:409-414)
+                return GLUExpert(d_model, d_ff, dropout)
+            return SharedMoELayer(GLUExpert(d_model, d_ff, dropout), d_model, n_experts=n_experts, n_experts_per_token=2,
+                                  dropout=dropout, balancing=balancing)
+
+        self.encoder = _Stack([_DecoderLayerV2(d_model, hd, ff(i), cross=False) for i in range(n_layers)], d_model)
+        self.decoder = _Stack([_DecoderLayerV2(d_model, hd, ff(i), cross=True) for i in range(n_layers)], d_model)
+        for q in self.parameters():
+            if q.dim() > 1:
+                nn.init.xavier_uniform_(q)
+
+    generate_square_subsequent_mask = staticmethod(_TransformerParams.generate_square_subsequent_mask)
+
+
+class VideoMusicTransformer_V2(nn.Module):
+    """Reference ``VideoMusicTransformer_V2`` (model/video_music_transformer.py:316-609) for ``version_name='2.2'``:
+    no additive positional encoding, RoPE (cache built for dim=d_model, applied through the raw (H, L, B, hd) view)
+    inside every attention, three GLU feed-forward layers then three SharedMoELayer(6 experts, top-2) layers in both
+    stacks, post-norm.  A composition of the library's operator kernels (``video2music_amd/ops.py``): every step of
+    ``generate`` re-runs ``forward`` like the reference does (:547-548); a KV-cached fast path is future work.
+    """
+
+    def __init__(self, version_name="2.0", n_layers=6, num_heads=8, d_model=512, dim_feedforward=1024, dropout=0.1,
+                 max_sequence_midi=2048, max_sequence_video=300, max_sequence_chord=300, total_vf_dim=0, rms_norm=False,
+                 scene_embed=False, chord_embed=False, dropTokenRate=0.0, balancing=False):
+        super().__init__()
+        if version_name != "2.2":
+            raise NotImplementedError("only version_name='2.2' (generate.py's default) is built; 2.0 / 2.1 / 2.3 are variants of it")
+        if scene_embed or chord_embed or dropTokenRate != 0.0 or rms_norm:
+            raise NotImplementedError("scene_embed / chord_embed / dropTokenRate / rms_norm are outside this path")
+        if n_layers < 3:
+            raise ValueError("the reference builds 3 shallow + (n_layers-3) deep layers")
+        self.nlayers, self.nhead, self.d_model, self.d_ff, self.dropout = n_layers, num_heads, d_model, dim_feedforward, dropout
+        self.max_seq_midi, self.max_seq_video, self.max_seq_chord = max_sequence_midi, max_sequence_video, max_sequence_chord
+        self.scene_embed, self.chord_embed, self.dropTokenRate, self.version_name = scene_embed, chord_embed, dropTokenRate, version_name
+        self.total_vf_dim = total_vf_dim
+        self.n_experts, self.n_experts_per_token = 6, 2
+        self.embedding = nn.Embedding(CHORD_SIZE, d_model)
+        self.embedding_root = nn.Embedding(CHORD_ROOT_SIZE, d_model)
+        self.embedding_attr = nn.Embedding(CHORD_ATTR_SIZE, d_model)
+        self.Linear_vis = nn.Linear(total_vf_dim, d_model)
+        self.Linear_chord = nn.Linear(d_model + 1, d_model)
+        self.condition_linear = nn.Linear(1, d_model)
+        self.transformer = _TransformerParamsV2(d_model, num_heads, n_layers, dim_feedforward, dropout, self.n_experts, balancing)
+        self.Wout = nn.Linear(d_model, CHORD_SIZE)
+        self.softmax = nn.Softmax(dim=-1)
+        from .rotate_operation import RotaryPositionalEmbeddings
+        rope = RotaryPositionalEmbeddings(d_model, max_sequence_video)      # dim = d_model, not head_dim (:380)
+        self.register_buffer("_rope_cache", rope.cache.clone(), persistent=False)
+        self._derived_sig = None
+
+    # ---- derived tensors (rebuilt when a parameter changes): Linear_chord tables, padded Linear_vis ----
+    def _derived(self):
+        from .. import ops
+        dev = self.Wout.weight.device
+        if dev.type != "cuda":
+            raise _lib.AmtError("VideoMusicTransformer_V2 runs on an MI355X only; video2music_amd has no CPU fallback")
+        sig = tuple((q.data_ptr(), q._version) for q in (self.Linear_chord.weight, self.embedding_root.weight,
+                                                           self.embedding_attr.weight, self.Linear_vis.weight))
+        if sig != self._derived_sig:
+            d, F = self.d_model, self.total_vf_dim
+            Wc = self.Linear_chord.weight.detach()
+            Wc_main = Wc[:, :d].contiguous()
+            self._wkey = Wc[:, d].contiguous()
+            self._PR = ops.linear(self.embedding_root.weight.detach().contiguous(), Wc_main)
+            self._PA = ops.linear(self.embedding_attr.weight.detach().contiguous(), Wc_main)
+            self._Fpad = (F + 31) // 32 * 32
+            Wv = torch.zeros(d, self._Fpad, device=dev)
+            Wv[:, :F] = self.Linear_vis.weight.detach()
+            self._Wvis_pad = Wv
+            self._zero_pe = torch.zeros(self.max_seq_chord, d, device=dev)
+            self._derived_sig = sig
+
+    def _attention(self, xq, xkv, a, Lq, Lk, B, causal, resid):
+        """xq (Lq*B, E), xkv (Lk*B, E) seq-first rows; returns out-proj(attn) + resid."""
+        from .. import ops
+        E, H = self.d_model, self.nhead
+        hd = E // H
+        W, b = a.in_proj_weight.detach(), a.in_proj_bias.detach()
+        q = ops.linear(xq, W[:E], b[:E])
+        k = ops.linear(xkv, W[E:2 * E], b[E:2 * E])
+        v = ops.linear(xkv, W[2 * E:], b[2 * E:])
+        q = ops.rope(q.view(H, Lq, B, hd), self._rope_cache).view(Lq * B, E)       # raw (H, L, B, hd) view (:1041-1053)
+        k = ops.rope(k.view(H, Lk, B, hd), self._rope_cache).view(Lk * B, E)
+        o = torch.empty(Lq * B, E, device=xq.device, dtype=torch.float32)
+        st = (E, hd, B * E) * 4                                                     # (L, B, E) buffers: b, h, l strides
+        ops.attention(q, k, v, st, B, H, Lq, Lk, hd, causal, 1.0 / math.sqrt(hd), o)
+        return ops.linear(o, a.out_proj.weight.detach(), a.out_proj.bias.detach(), resid=resid)
+
+    def _ff(self, x, ff, L, B):
+        from .. import ops
+        from .moe import GLUExpert
+        if isinstance(ff, GLUExpert):
+            return ops.glu(x, ff)
+        return ff(x.view(L, B, self.d_model)).reshape(L * B, self.d_model)
+
+    def forward(self, x, x_root, x_attr, feature_semantic_list, feature_key, feature_scene_offset, feature_motion,
+                feature_emotion, mask=True):
+        from .. import ops
+        if mask is not True:
+            raise NotImplementedError("forward(mask=False) is not used by any reference caller")
+        self._derived()
+        dev = self.Wout.weight.device
+        f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+        sem, scene, emotion, motion = f32(feature_semantic_list), f32(feature_scene_offset), f32(feature_emotion), f32(feature_motion)
+        if motion.dim() == 2:
+            motion = motion.unsqueeze(-1).contiguous()
+        B, L = x_root.shape
+        S = sem.shape[1]
+        if max(L, S) > self.max_seq_video:
+            raise ValueError(f"sequence longer than the RoPE cache ({self.max_seq_video}), like in the reference")
+        key = f32(feature_key).reshape(-1)
+        key = key.expand(B).contiguous() if key.numel() == 1 else key
+        d = self.d_model
+        ln = lambda t, n, resid=None: ops.layernorm(t, n.weight.detach(), n.bias.detach(), resid=resid, eps=n.eps)
+        # input stage (:445-487), then seq-first (:490-491)
+        xf = ops.chord_embed(x_root.to(dev).long().contiguous(), x_attr.to(dev).long().contiguous(), key, self._PR, self._PA,
+                             self._wkey, self.Linear_chord.bias.detach(), self._zero_pe)
+        vf = ops.linear(ops.concat_features(sem, scene, motion, emotion, self._Fpad), self._Wvis_pad, self.Linear_vis.bias.detach())
+        t = xf.view(B, L, d).permute(1, 0, 2).contiguous().view(L * B, d)
+        src = vf.view(B, S, d).permute(1, 0, 2).contiguous().view(S * B, d)
+        for lyr in self.transformer.encoder.layers:
+            src = ln(self._attention(src, src, lyr.self_attn, S, S, B, False, src), lyr.norm1)
+            src = ln(self._ff(src, lyr.ff, S, B), lyr.norm2, resid=src)
+        memory = ln(src, self.transformer.encoder.norm)
+        for lyr in self.transformer.decoder.layers:
+            t = ln(self._attention(t, t, lyr.self_attn, L, L, B, True, t), lyr.norm1)
+            t = ln(self._attention(t, memory, lyr.cross_attn, L, S, B, False, t), lyr.norm2)
+            t = ln(self._ff(t, lyr.ff, L, B), lyr.norm3, resid=t)
+        t = ln(t, self.transformer.decoder.norm)
+        t = t.view(L, B, d).permute(1, 0, 2).contiguous().view(B * L, d)
+        return ops.linear(t, self.Wout.weight.detach(), self.Wout.bias.detach()).view(B, L, CHORD_SIZE)
+
+    def generate(self, feature_semantic_list=[], feature_key=None, feature_scene_offset=None, feature_motion=None,
+                 feature_emotion=None, primer=None, primer_root=None, primer_attr=None, target_seq_length=300, beam=0,
+                 beam_chance=1.0, max_conseq_N=0, max_conseq_chord=2, temperature=1.0, sampler="categorical"):
+        """Reference loop (:518-609): one clip, full re-forward every step, decision on the host like the reference's
+        python loop (softmax[:157] / temperature, N and repeat suppression, Categorical sample or arg-max)."""
+        from ..utilities.constants import chord_to_root_attr
+        assert (not self.training), "Cannot generate while in training mode"
+        if beam not in (0, 1):
+            raise NotImplementedError("beam > 1 is not implemented (generate.py:347-349 asserts it out as well)")
+        print("Generating sequence of max length:", target_seq_length)
+        dev = self.Wout.weight.device
+        T = int(target_seq_length)
+        gen = torch.full((1, T), CHORD_PAD, dtype=torch.long)
+        gen_root = torch.full((1, T), CHORD_ROOT_PAD, dtype=torch.long)
+        gen_attr = torch.full((1, T), CHORD_ATTR_PAD, dtype=torch.long)
+        P = len(primer)
+        gen[0, :P], gen_root[0, :P], gen_attr[0, :P] = primer.cpu().long(), primer_root.cpu().long(), primer_attr.cpu().long()
+        cur = P
+        while cur < T:
+            logits = self.forward(gen[:, :cur], gen_root[:, :cur], gen_attr[:, :cur], feature_semantic_list, feature_key,
+                                  feature_scene_offset, feature_motion, feature_emotion)
+            row = logits[0, cur - 1].cpu()
+            probs = torch.softmax(row / temperature, dim=-1)[:CHORD_END]
+            if beam == 1:
+                gen[0, cur] = int(torch.topk(probs, 1)[1][0])
+            else:
+                if max_conseq_N == 0:
+                    probs[0] = 0.0
+                if cur >= max_conseq_chord and all(int(gen[0, cur - 1]) == int(gen[0, cur - 1 - k]) for k in range(1, max_conseq_chord)):
+                    probs[int(gen[0, cur - 1])] = 0.0
+                if sampler == "argmax":
+                    tok = int((probs / probs.sum()).argmax())
+                else:
+                    tok = int(torch.distributions.categorical.Categorical(probs=probs).sample())
+                gen[0, cur] = tok
+                gen_root[0, cur], gen_attr[0, cur] = chord_to_root_attr(tok)
+            cur += 1
+        return gen[:, :cur].to(dev)

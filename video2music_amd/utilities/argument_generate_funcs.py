@@ -26,9 +26,9 @@ def parse_generate_args(argv=None):
     parser.add_argument("-d_model", type=int, default=512)
     parser.add_argument("-dim_feedforward", type=int, default=1024)
     parser.add_argument("-rms_norm", type=bool, default=False)
-    parser.add_argument("-music_gen_version", type=str, default=None,
-                        help="None selects the base AMT (VideoMusicTransformer), the model of this build; "
-                             "the reference default '2.2' selects VideoMusicTransformer_V2 (SURVEY.md §8 f1, not built yet)")
+    parser.add_argument("-music_gen_version", type=str, default="2.2",
+                        help="'2.2' (reference default): VideoMusicTransformer_V2; 'None': the base AMT (VideoMusicTransformer, "
+                             "the batched KV-cached fast path)")
     parser.add_argument("-scene_embed", type=bool, default=False)
     parser.add_argument("-is_video", type=bool, default=IS_VIDEO)
     parser.add_argument("-emo_model", type=str, default="6c_l14p")
