@@ -412,8 +412,9 @@ class VideoMusicTransformer_V2(nn.Module):
     """Reference ``VideoMusicTransformer_V2`` (model/video_music_transformer.py:316-609) for ``version_name='2.2'``:
     no additive positional encoding, RoPE (cache built for dim=d_model, applied through the raw (H, L, B, hd) view)
     inside every attention, three GLU feed-forward layers then three SharedMoELayer(6 experts, top-2) layers in both
-    stacks, post-norm.  A composition of the library's operator kernels (``video2music_amd/ops.py``): every step of
-    ``generate`` re-runs ``forward`` like the reference does (:547-548); a KV-cached fast path is future work.
+    stacks, post-norm.  A composition of the library's operator kernels (``video2music_amd/ops.py``): ``generate`` runs the
+    video encoder once and re-runs the decoder stack every step (the reference re-runs both, :547-548); a KV-cached,
+    graph-captured decode is future work.
     """
 
     def __init__(self, version_name="2.0", n_layers=6, num_heads=8, d_model=512, dim_feedforward=1024, dropout=0.1,
@@ -490,42 +491,56 @@ class VideoMusicTransformer_V2(nn.Module):
             return ops.glu(x, ff)
         return ff(x.view(L, B, self.d_model)).reshape(L * B, self.d_model)
 
-    def forward(self, x, x_root, x_attr, feature_semantic_list, feature_key, feature_scene_offset, feature_motion,
-                feature_emotion, mask=True):
+    def _ln(self, t, n, resid=None):
         from .. import ops
-        if mask is not True:
-            raise NotImplementedError("forward(mask=False) is not used by any reference caller")
+        return ops.layernorm(t, n.weight.detach(), n.bias.detach(), resid=resid, eps=n.eps)
+
+    def _encode_memory(self, feature_semantic_list, feature_scene_offset, feature_motion, feature_emotion):
+        """Video stream + encoder stack (:455-487 and the encoder half of :505): (S*B, d) seq-first rows, B, S."""
+        from .. import ops
         self._derived()
         dev = self.Wout.weight.device
         f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
         sem, scene, emotion, motion = f32(feature_semantic_list), f32(feature_scene_offset), f32(feature_emotion), f32(feature_motion)
         if motion.dim() == 2:
             motion = motion.unsqueeze(-1).contiguous()
-        B, L = x_root.shape
-        S = sem.shape[1]
-        if max(L, S) > self.max_seq_video:
-            raise ValueError(f"sequence longer than the RoPE cache ({self.max_seq_video}), like in the reference")
-        key = f32(feature_key).reshape(-1)
-        key = key.expand(B).contiguous() if key.numel() == 1 else key
-        d = self.d_model
-        ln = lambda t, n, resid=None: ops.layernorm(t, n.weight.detach(), n.bias.detach(), resid=resid, eps=n.eps)
-        # input stage (:445-487), then seq-first (:490-491)
-        xf = ops.chord_embed(x_root.to(dev).long().contiguous(), x_attr.to(dev).long().contiguous(), key, self._PR, self._PA,
-                             self._wkey, self.Linear_chord.bias.detach(), self._zero_pe)
+        B, S, d = sem.shape[0], sem.shape[1], self.d_model
+        if S > self.max_seq_video:
+            raise ValueError(f"video longer than the RoPE cache ({self.max_seq_video}), like in the reference")
         vf = ops.linear(ops.concat_features(sem, scene, motion, emotion, self._Fpad), self._Wvis_pad, self.Linear_vis.bias.detach())
-        t = xf.view(B, L, d).permute(1, 0, 2).contiguous().view(L * B, d)
         src = vf.view(B, S, d).permute(1, 0, 2).contiguous().view(S * B, d)
         for lyr in self.transformer.encoder.layers:
-            src = ln(self._attention(src, src, lyr.self_attn, S, S, B, False, src), lyr.norm1)
-            src = ln(self._ff(src, lyr.ff, S, B), lyr.norm2, resid=src)
-        memory = ln(src, self.transformer.encoder.norm)
+            src = self._ln(self._attention(src, src, lyr.self_attn, S, S, B, False, src), lyr.norm1)
+            src = self._ln(self._ff(src, lyr.ff, S, B), lyr.norm2, resid=src)
+        return self._ln(src, self.transformer.encoder.norm), B, S
+
+    def _decode(self, x_root, x_attr, feature_key, memory, B, S):
+        """Chord stream + decoder stack + Wout (:437-452, :490-516) over a precomputed encoder memory."""
+        from .. import ops
+        dev = self.Wout.weight.device
+        L, d = x_root.shape[1], self.d_model
+        if L > self.max_seq_video:
+            raise ValueError(f"chord sequence longer than the RoPE cache ({self.max_seq_video}), like in the reference")
+        key = feature_key.to(device=dev, dtype=torch.float32).reshape(-1)
+        key = key.expand(B).contiguous() if key.numel() == 1 else key.contiguous()
+        xf = ops.chord_embed(x_root.to(dev).long().contiguous(), x_attr.to(dev).long().contiguous(), key, self._PR, self._PA,
+                             self._wkey, self.Linear_chord.bias.detach(), self._zero_pe)
+        t = xf.view(B, L, d).permute(1, 0, 2).contiguous().view(L * B, d)
         for lyr in self.transformer.decoder.layers:
-            t = ln(self._attention(t, t, lyr.self_attn, L, L, B, True, t), lyr.norm1)
-            t = ln(self._attention(t, memory, lyr.cross_attn, L, S, B, False, t), lyr.norm2)
-            t = ln(self._ff(t, lyr.ff, L, B), lyr.norm3, resid=t)
-        t = ln(t, self.transformer.decoder.norm)
+            t = self._ln(self._attention(t, t, lyr.self_attn, L, L, B, True, t), lyr.norm1)
+            t = self._ln(self._attention(t, memory, lyr.cross_attn, L, S, B, False, t), lyr.norm2)
+            t = self._ln(self._ff(t, lyr.ff, L, B), lyr.norm3, resid=t)
+        t = self._ln(t, self.transformer.decoder.norm)
         t = t.view(L, B, d).permute(1, 0, 2).contiguous().view(B * L, d)
         return ops.linear(t, self.Wout.weight.detach(), self.Wout.bias.detach()).view(B, L, CHORD_SIZE)
+
+    def forward(self, x, x_root, x_attr, feature_semantic_list, feature_key, feature_scene_offset, feature_motion,
+                feature_emotion, mask=True):
+        if mask is not True:
+            raise NotImplementedError("forward(mask=False) is not used by any reference caller")
+        memory, B, S = self._encode_memory(feature_semantic_list, feature_scene_offset, feature_motion, feature_emotion)
+        assert x_root.shape[0] == B, f"{x_root.shape[0]} chord sequences but {B} clips of video features"
+        return self._decode(x_root, x_attr, feature_key, memory, B, S)
 
     def generate(self, feature_semantic_list=[], feature_key=None, feature_scene_offset=None, feature_motion=None,
                  feature_emotion=None, primer=None, primer_root=None, primer_attr=None, target_seq_length=300, beam=0,
@@ -545,9 +560,12 @@ class VideoMusicTransformer_V2(nn.Module):
         P = len(primer)
         gen[0, :P], gen_root[0, :P], gen_attr[0, :P] = primer.cpu().long(), primer_root.cpu().long(), primer_attr.cpu().long()
         cur = P
+        # the encoder output does not depend on the chords: it is computed once instead of every step (the reference
+        # recomputes the identical tensor inside each forward, :547-548)
+        memory, B, S = self._encode_memory(feature_semantic_list, feature_scene_offset, feature_motion, feature_emotion)
+        assert B == 1, "generate takes one clip, like the reference (:528-530)"
         while cur < T:
-            logits = self.forward(gen[:, :cur], gen_root[:, :cur], gen_attr[:, :cur], feature_semantic_list, feature_key,
-                                  feature_scene_offset, feature_motion, feature_emotion)
+            logits = self._decode(gen_root[:, :cur], gen_attr[:, :cur], feature_key, memory, B, S)
             row = logits[0, cur - 1].cpu()
             probs = torch.softmax(row / temperature, dim=-1)[:CHORD_END]
             if beam == 1:
