@@ -182,3 +182,62 @@ def test_bad_arguments_fail_loudly():
         _lib.call("amt_linear_fwd", _lib.ptr(x), _lib.ptr(x), None, None, _lib.ptr(x), 4, 4, 48, 0, sp())
     with pytest.raises(_lib.AmtError):       # unsupported head dim
         _lib.call("amt_cross_attn_fwd", _lib.ptr(x), _lib.ptr(x), _lib.ptr(x), _lib.ptr(x), 1, 1, 4, 4, 48, 0, sp())
+
+
+def test_attention_random_shape_sweep():
+    """Seeded sweep over ragged shapes (lengths not multiples of the 32-key tile / 128-query block, B and H > 1)."""
+    rs = np.random.RandomState(2024)
+    for case in range(24):
+        hd = int(rs.choice([32, 64, 128]))
+        H = int(rs.choice([1, 2, 4]))
+        B = int(rs.randint(1, 4))
+        rpr = bool(case % 2)
+        Lq = int(rs.randint(1, 200))
+        Lk = Lq if rpr else int(rs.randint(1, 340))
+        causal = 1 if rpr else int(rs.randint(0, 2)) if Lq == Lk else 0
+        E = H * hd
+        q, k, v = rnd(rs, B, Lq, E, scale=0.5), rnd(rs, B, Lk, E), rnd(rs, B, Lk, E)
+        qh, kh, vh = (O.split_heads(t.double(), H) for t in (q, k, v))
+        s = qh @ kh.transpose(-1, -2)
+        er_len = Lq + int(rs.randint(0, 9))
+        Er = torch.from_numpy(rs.uniform(size=(er_len, hd)).astype(np.float32))
+        if rpr:
+            s = s + O.skew(torch.einsum("bhld,md->bhlm", qh, Er[er_len - Lq:].double()))
+        if causal:
+            s = s + torch.triu(torch.full((Lq, Lk), float("-inf"), dtype=s.dtype), diagonal=1)
+        ref = O.merge_heads(torch.softmax(s, -1) @ vh)
+        o = torch.empty(B, Lq, E, device="cuda")
+        dq, dk, dv, de = dev(q), dev(k), dev(v), dev(Er)
+        if rpr:
+            _lib.call("amt_rpr_attn_fwd", _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(de), _lib.ptr(o), B, H, Lq, hd, er_len, sp())
+        else:
+            _lib.call("amt_cross_attn_fwd", _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(o), B, H, Lq, Lk, hd, causal, sp())
+        err = (o.cpu().double() - ref).abs().max().item()
+        assert err < 3e-5, (case, B, H, Lq, Lk, hd, rpr, causal, err)
+
+
+def test_attention_decode_random_sweep():
+    rs = np.random.RandomState(77)
+    for case in range(24):
+        hd = int(rs.choice([16, 32, 64, 128]))
+        H = int(rs.choice([1, 2, 8]))
+        B = int(rs.randint(1, 33))
+        cap = int(rs.randint(1, 400))
+        pos = int(rs.randint(0, cap))
+        rpr = bool(case % 2)
+        er_len = cap + int(rs.randint(0, 5))
+        q = rnd(rs, B, H * hd, scale=0.5)
+        kc, vc = rnd(rs, B, H, cap, hd), rnd(rs, B, H, cap, hd)
+        Er = torch.from_numpy(rs.uniform(size=(er_len, hd)).astype(np.float32))
+        qh = q.view(B, H, 1, hd).double()
+        s = qh @ kc[:, :, :pos + 1].double().transpose(-1, -2)
+        if rpr:
+            idx = er_len - 1 - (pos - torch.arange(pos + 1))
+            s = s + torch.einsum("bhqd,jd->bhqj", qh, Er[idx].double())
+        ref = (torch.softmax(s, -1) @ vc[:, :, :pos + 1].double()).reshape(B, H * hd)
+        o = torch.empty(B, H * hd, device="cuda")
+        dq, dk, dv, de = dev(q), dev(kc), dev(vc), dev(Er) if rpr else None
+        _lib.call("amt_attn_decode_fwd", _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(de), _lib.ptr(o), B, H, hd, cap, pos,
+                  er_len if rpr else 0, sp())
+        err = (o.cpu().double() - ref).abs().max().item()
+        assert err < 3e-5, (case, B, H, hd, cap, pos, rpr, err)
