@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -48,6 +49,11 @@ struct DecLayer {   // raw + packed weights of one decoder layer
     const float *sa_w, *sa_b, *Er, *sa_ow, *sa_ob, *ca_w, *ca_b, *ca_ow, *ca_ob, *l1w, *l1b, *l2w, *l2b;
     const float *n1w, *n1b, *n2w, *n2b, *n3w, *n3b;
     float *p_sa, *p_sao, *p_caq, *p_cao, *p_l1, *p_l2;   // MFMA-ordered copies for the decode step
+    // LayerNorm folded through the following projection (fold.hip): packed [Wc | W'] and the vectors g | c | dv
+    //   a: norm1 -> cross-attention query        (N = d,   K = d + d)
+    //   b: norm2 -> linear1                       (N = dff, K = d + d)
+    //   c: norm3 -> next layer's self-attn in-proj (N = 3d, K = dff + d), absent in the last layer
+    float *pf_a, *pf_b, *pf_c, *va, *vb, *vc;
 };
 struct EncLayer {
     const float *sa_w, *sa_b, *sa_ow, *sa_ob, *l1w, *l1b, *l2w, *l2b, *n1w, *n1b, *n2w, *n2b;
@@ -79,6 +85,9 @@ struct amt_handle {
     size_t kvc_layer = 0, kvc_part = 0;
     float *x_in = nullptr, *u1 = nullptr, *u2 = nullptr, *u3 = nullptr, *xa = nullptr, *xb = nullptr, *xc = nullptr;
     float *qb = nullptr, *ob = nullptr, *hb = nullptr, *keyb = nullptr;
+    bool fold = false;                   // decode chain with folded LayerNorms (5 kernels per layer instead of 8)
+    float *qraw = nullptr, *hraw = nullptr, *qkvraw = nullptr;          // raw projections of the un-normalised sums
+    float *tWs = nullptr, *tT = nullptr, *tWc = nullptr, *tComb = nullptr;   // load-time scratch of build_fold
     int* pos = nullptr;
     unsigned* ticket = nullptr;
     int64_t *tokens = nullptr, *roots = nullptr, *attrs = nullptr;   // [maxB][Tcap]
@@ -129,6 +138,23 @@ int32_t pack(amt_handle* h, const float* w, int N, int K, float** out, hipStream
         if (rc) return rc;
     }
     return amt_launch_pack_weight(w, *out, N, K, s);
+}
+
+// Folds LayerNorm(gamma, beta) of u = A.Wo^T + bo + r through y = LN(u).W^T + b (see fold.hip):
+// packed <- [W'.Wo | W'] (N x (Kin + d)), vec <- g | c | dv (3N floats).  W: [N][d], Wo: [d][Kin].
+int32_t build_fold(amt_handle* h, const float* Wm, int N, const float* gamma, const float* beta, const float* b,
+                   const float* Wo, int Kin, const float* bo, float** packed, float** vec, hipStream_t s) {
+    const int d = h->d;
+    int32_t rc;
+    if (!*vec && (rc = dev_alloc(h, vec, (size_t)3 * N))) return rc;
+    if ((rc = amt_launch_scale_cols(Wm, gamma, h->tWs, N, d, s))) return rc;
+    if ((rc = amt_launch_transpose(Wo, h->tT, d, Kin, s))) return rc;                       // [Kin][d]
+    if ((rc = amt_launch_gemm(gemm_params(h->tWs, d, h->tT, d, h->tWc, Kin, N, Kin, d, nullptr), s))) return rc;
+    const size_t ld = (size_t)(Kin + d) * sizeof(float);
+    AMT_HIP(hipMemcpy2DAsync(h->tComb, ld, h->tWc, (size_t)Kin * sizeof(float), (size_t)Kin * sizeof(float), N, hipMemcpyDeviceToDevice, s));
+    AMT_HIP(hipMemcpy2DAsync(h->tComb + Kin, ld, h->tWs, (size_t)d * sizeof(float), (size_t)d * sizeof(float), N, hipMemcpyDeviceToDevice, s));
+    if ((rc = pack(h, h->tComb, N, Kin + d, packed, s))) return rc;
+    return amt_launch_fold_vectors(Wm, h->tWs, beta, b, bo, *vec, *vec + N, *vec + 2 * N, N, d, s);
 }
 
 int32_t ensure_workspace(amt_handle* h) {
@@ -199,8 +225,85 @@ struct StepProf {
 #define PROF_BEGIN() do { if (prof) prof->begin(); } while (0)
 #define PROF_END(c) do { if (prof) prof->end(c); } while (0)
 
+// One decode step with every LayerNorm folded through the projection behind it (fold.hip): per layer
+//   SA  self-attention; layers > 0 finish norm3 of the previous layer in the prologue (q, new k/v, residual row)
+//   G1  [u1 | q_raw]   = [o | r] . [Wo | Wc_a,W'_a]      out-proj + residual, and the raw cross-attention query
+//   CA  cross-attention, norm1 finished in the prologue
+//   G2  [u2 | h_raw]   = [o | x1] . [Wo | Wc_b,W'_b]     out-proj + residual, and the raw FFN-up activations
+//   G3  [u3 | qkv_raw] = [relu(norm2-fix(h_raw)) | x2] . [W2 | Wc_c,W'_c]   FFN-down + residual, next layer's raw QKV
+// 5 dependent kernels per layer instead of 8 (layer 0 keeps its plain QKV projection in front).
+int32_t enqueue_decoder_step_folded(amt_handle* h, hipStream_t s, StepProf* prof) {
+    const int B = h->genB, d = h->d, dff = h->dff, H = h->H, hd = h->hd;
+    const float qscale = 1.0f / sqrtf((float)hd);
+    int32_t rc;
+    for (int l = 0; l < h->nl; ++l) {
+        const DecLayer& L = h->dec[l];
+        float* Kc = h->KVc + (size_t)l * h->kvc_layer;
+        float* Vc = Kc + h->kvc_part;
+        const float* Kx = h->KVx + (size_t)l * h->kvx_layer;
+        const float* Vx = Kx + h->kvx_part;
+        AttnDecodeParams a{};
+        a.k = Kc; a.v = Vc; a.o = h->ob; a.B = B; a.H = H; a.hd = hd; a.cap = h->Tcap;
+        a.pos = h->pos; a.Er = L.Er; a.er_len = h->Tcap;
+        if (l == 0) {
+            DecodeGemmParams g{};
+            g.B = B; g.eps = LN_EPS; g.x = h->x_in; g.ldx = d; g.Wp = L.p_sa; g.bias = L.sa_b; g.N = 3 * d; g.K = d;
+            g.mode = 1; g.y = h->qb; g.ldy = d; g.scale = qscale; g.scale_cols = d;
+            g.kcache = Kc; g.vcache = Vc; g.H = H; g.hd = hd; g.cap = h->Tcap; g.pos = h->pos; g.d = d;
+            PROF_BEGIN();
+            if ((rc = amt_launch_decode_gemm(g, s))) return rc;
+            PROF_END(2);
+            a.q = h->qb;
+        } else {
+            const DecLayer& P = h->dec[l - 1];
+            a.q = h->qkvraw; a.ldq = 3 * d; a.d = d; a.fold_u = h->u3; a.fold_g = P.vc; a.fold_c = P.vc + 3 * d;
+            a.fold_lnw = P.n3w; a.fold_lnb = P.n3b; a.xn = h->xa; a.new_kv = 1; a.k_new = Kc; a.v_new = Vc;
+            a.eps = LN_EPS; a.q_scale = qscale;
+        }
+        if (!(h->skip_mask & 1)) {
+            PROF_BEGIN();
+            if ((rc = amt_launch_attn_decode(a, s))) return rc;
+            PROF_END(0);
+        }
+        const float* r0 = l == 0 ? h->x_in : h->xa;
+        DecodeGemmParams g1{};
+        g1.B = B; g1.eps = LN_EPS; g1.scale = 1.f; g1.x = h->ob; g1.ldx = d; g1.x2 = r0; g1.ldx2 = d; g1.K1 = d; g1.K = 2 * d;
+        g1.Wp = L.p_sao; g1.bias = L.sa_ob; g1.resid = r0; g1.ldr = d; g1.y = h->u1; g1.ldy = d;
+        g1.n_split = d; g1.N = 2 * d; g1.Wp2 = L.pf_a; g1.bias2 = L.va + 2 * d; g1.y2 = h->qraw; g1.ldy2 = d;
+        PROF_BEGIN();
+        if ((rc = amt_launch_decode_gemm(g1, s))) return rc;
+        PROF_END(2);
+        AttnDecodeParams x{};
+        x.k = Kx; x.v = Vx; x.o = h->ob; x.B = B; x.H = H; x.hd = hd; x.cap = h->Scap; x.n_keys = h->encS;
+        x.q = h->qraw; x.ldq = d; x.d = d; x.fold_u = h->u1; x.fold_g = L.va; x.fold_c = L.va + d;
+        x.fold_lnw = L.n1w; x.fold_lnb = L.n1b; x.xn = h->xb; x.eps = LN_EPS; x.q_scale = qscale;
+        if (!(h->skip_mask & 2)) {
+            PROF_BEGIN();
+            if ((rc = amt_launch_attn_decode(x, s))) return rc;
+            PROF_END(1);
+        }
+        DecodeGemmParams g2{};
+        g2.B = B; g2.eps = LN_EPS; g2.scale = 1.f; g2.x = h->ob; g2.ldx = d; g2.x2 = h->xb; g2.ldx2 = d; g2.K1 = d; g2.K = 2 * d;
+        g2.Wp = L.p_cao; g2.bias = L.ca_ob; g2.resid = h->xb; g2.ldr = d; g2.y = h->u2; g2.ldy = d;
+        g2.n_split = d; g2.N = d + dff; g2.Wp2 = L.pf_b; g2.bias2 = L.vb + 2 * dff; g2.y2 = h->hraw; g2.ldy2 = dff;
+        PROF_BEGIN();
+        if ((rc = amt_launch_decode_gemm(g2, s))) return rc;
+        PROF_END(2);
+        DecodeGemmParams g3{};
+        g3.B = B; g3.eps = LN_EPS; g3.scale = 1.f; g3.pro = 1; g3.x = h->hraw; g3.ldx = dff; g3.x2 = h->u2; g3.ldx2 = d;
+        g3.K1 = dff; g3.K = dff + d; g3.fold_g = L.vb; g3.fold_c = L.vb + dff; g3.ln_w = L.n2w; g3.ln_b = L.n2b;
+        g3.Wp = L.p_l2; g3.bias = L.l2b; g3.y = h->u3; g3.ldy = d; g3.n_split = d; g3.N = d;
+        if (l + 1 < h->nl) { g3.N = 4 * d; g3.Wp2 = L.pf_c; g3.bias2 = L.vc + 6 * d; g3.y2 = h->qkvraw; g3.ldy2 = 3 * d; }
+        PROF_BEGIN();
+        if ((rc = amt_launch_decode_gemm(g3, s))) return rc;
+        PROF_END(2);
+    }
+    return 0;
+}
+
 // the kernels of one decode step up to (not including) the sampling head
 int32_t enqueue_decoder_step(amt_handle* h, hipStream_t s, StepProf* prof = nullptr) {
+    if (h->fold) return enqueue_decoder_step_folded(h, s, prof);
     const int B = h->genB, d = h->d, dff = h->dff, H = h->H, hd = h->hd;
     const float qscale = 1.0f / sqrtf((float)hd);
     int32_t rc;
@@ -446,6 +549,19 @@ extern "C" int32_t amt_finalize(amt_handle* h) {
         if ((rc = dev_alloc(h, &h->qb, bd))) return rc;
         if ((rc = dev_alloc(h, &h->ob, bd))) return rc;
         if ((rc = dev_alloc(h, &h->hb, (size_t)32 * dff))) return rc;
+        // folded chain: K = 2d and dff + d must fit the skinny GEMM, d the attention prologue
+        const char* chain = getenv("AMT_DECODE_CHAIN");
+        h->fold = !(chain && strcmp(chain, "plain") == 0) && d % 32 == 0 && d <= 1024 && (dff + d) % 64 == 0 && dff + d <= 1536 && dff % 16 == 0;
+        if (h->fold) {
+            if ((rc = dev_alloc(h, &h->qraw, bd))) return rc;
+            if ((rc = dev_alloc(h, &h->hraw, (size_t)32 * dff))) return rc;
+            if ((rc = dev_alloc(h, &h->qkvraw, 3 * bd))) return rc;
+            const size_t nmax = (size_t)std::max(3 * d, dff), kmax = (size_t)std::max(d, dff);
+            if ((rc = dev_alloc(h, &h->tWs, nmax * d))) return rc;
+            if ((rc = dev_alloc(h, &h->tT, kmax * d))) return rc;
+            if ((rc = dev_alloc(h, &h->tWc, nmax * kmax))) return rc;
+            if ((rc = dev_alloc(h, &h->tComb, nmax * (kmax + d)))) return rc;
+        }
         if ((rc = dev_alloc(h, &h->keyb, (size_t)32))) return rc;
         if ((rc = dev_alloc(h, &h->pos, (size_t)4))) return rc;
         if ((rc = dev_alloc(h, &h->ticket, (size_t)4))) return rc;
@@ -472,6 +588,14 @@ extern "C" int32_t amt_finalize(amt_handle* h) {
         if ((rc = pack(h, D.ca_ow, (int)d, (int)d, &D.p_cao, s))) return rc;
         if ((rc = pack(h, D.l1w, (int)dff, (int)d, &D.p_l1, s))) return rc;
         if ((rc = pack(h, D.l2w, (int)d, (int)dff, &D.p_l2, s))) return rc;
+        if (h->fold) {
+            if ((rc = build_fold(h, D.ca_w, (int)d, D.n1w, D.n1b, D.ca_b, D.sa_ow, (int)d, D.sa_ob, &D.pf_a, &D.va, s))) return rc;
+            if ((rc = build_fold(h, D.l1w, (int)dff, D.n2w, D.n2b, D.l1b, D.ca_ow, (int)d, D.ca_ob, &D.pf_b, &D.vb, s))) return rc;
+            if (l + 1 < h->nl) {
+                const DecLayer& Nx = h->dec[l + 1];
+                if ((rc = build_fold(h, Nx.sa_w, 3 * (int)d, D.n3w, D.n3b, Nx.sa_b, D.l2w, (int)dff, D.l2b, &D.pf_c, &D.vc, s))) return rc;
+            }
+        }
     }
     AMT_HIP(hipDeviceSynchronize());
     // captured graphs hold pointers that stay valid (weights reload in place), nothing to invalidate

@@ -80,7 +80,10 @@ __device__ __forceinline__ void consume_batch(const Batch<HD>& bt, const float4 
     }
 }
 
-template <int HD, bool RPR, bool NT>
+constexpr int UCH = 4;           // folded prologue: the pre-LN row has at most UCH*256 floats
+
+// FOLD: 0 plain query, 1 folded-LayerNorm prologue, 2 the same plus the new key/value of this position
+template <int HD, bool RPR, bool NT, int FOLD>
 __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnDecodeParams p) {
     constexpr int LPK = HD / 4;          // lanes per key row
     constexpr int KPW = 64 / LPK;        // keys per wave-instruction
@@ -99,11 +102,76 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnDecodeParams p
     // read (rows past the current length are fetched but never used; they lie inside the cache).
     Batch<HD> b0, b1;
     int j0 = wave * KPW;
-    load_kv<HD, NT>(b0, kb, vb, j0, sub, p.cap);
-    const float4 q4 = ld4(p.q + ((size_t)b * p.H + h) * HD + c * 4);
-    const int t = p.pos ? *p.pos : (p.n_keys - 1);
-    const int n_keys = t + 1;
+    const int t = p.pos ? *p.pos : (p.n_keys - 1);   // issued here: the prologue's stores would pin it behind them
+    float4 q4, kn4 = make_float4(0.f, 0.f, 0.f, 0.f), vn4 = kn4;
+    // Vector loads return in issue order.  The long prologue of FOLD 2 (11 loads and their address math) goes
+    // behind the first K/V batch so that the stream starts at once; the short one of FOLD 1 goes in front of it
+    // so that the statistics are computed while the batch is in flight (measured both ways).
+    if (FOLD != 1) load_kv<HD, NT>(b0, kb, vb, j0, sub, p.cap);
+    if (!FOLD) {
+        q4 = ld4(p.q + ((size_t)b * p.H + h) * HD + c * 4);
+    } else {
+        // LayerNorm folded through the projection: q = ((raw - mu*g) * rstd + c) * q_scale with the row
+        // statistics of the pre-LN sum u[b] (every wave recomputes them: d floats from L2, two DPP reductions).
+        const int d = p.d, col = h * HD + c * 4;
+        const float* ub = p.fold_u + (size_t)b * d;
+        float4 uv[UCH];
+#pragma unroll
+        for (int i = 0; i < UCH; ++i) {
+            const int k = (i * 64 + lane) * 4;
+            uv[i] = k < d ? ld4(ub + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float* raw = p.q + (size_t)b * p.ldq + col;
+        const float4 rq = ld4(raw), gq = ld4(p.fold_g + col), cq = ld4(p.fold_c + col);
+        float4 rk = kn4, gk = kn4, ck = kn4, rv = kn4, gv = kn4, cv = kn4;
+        if (FOLD == 2) {
+            rk = ld4(raw + d); gk = ld4(p.fold_g + d + col); ck = ld4(p.fold_c + d + col);
+            rv = ld4(raw + 2 * d); gv = ld4(p.fold_g + 2 * d + col); cv = ld4(p.fold_c + 2 * d + col);
+        }
+        if (FOLD == 1) load_kv<HD, NT>(b0, kb, vb, j0, sub, p.cap);
+        const float inv_d = 1.0f / (float)d;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < UCH; ++i) s += (uv[i].x + uv[i].y) + (uv[i].z + uv[i].w);
+        const float mean = wave_sum(s) * inv_d;
+        float qq = 0.f;
+#pragma unroll
+        for (int i = 0; i < UCH; ++i) {
+            if ((i * 64 + lane) * 4 < d) {
+                const float dx = uv[i].x - mean, dy = uv[i].y - mean, dz = uv[i].z - mean, dw = uv[i].w - mean;
+                qq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(qq) * inv_d + p.eps);
+        q4.x = ((rq.x - mean * gq.x) * rstd + cq.x) * p.q_scale; q4.y = ((rq.y - mean * gq.y) * rstd + cq.y) * p.q_scale;
+        q4.z = ((rq.z - mean * gq.z) * rstd + cq.z) * p.q_scale; q4.w = ((rq.w - mean * gq.w) * rstd + cq.w) * p.q_scale;
+        if (FOLD == 2) {
+            kn4.x = (rk.x - mean * gk.x) * rstd + ck.x; kn4.y = (rk.y - mean * gk.y) * rstd + ck.y;
+            kn4.z = (rk.z - mean * gk.z) * rstd + ck.z; kn4.w = (rk.w - mean * gk.w) * rstd + ck.w;
+            vn4.x = (rv.x - mean * gv.x) * rstd + cv.x; vn4.y = (rv.y - mean * gv.y) * rstd + cv.y;
+            vn4.z = (rv.z - mean * gv.z) * rstd + cv.z; vn4.w = (rv.w - mean * gv.w) * rstd + cv.w;
+        }
+        if (p.xn && h == 0 && wave == 0) {        // LayerNorm(u[b]): the residual of the following block
+#pragma unroll
+            for (int i = 0; i < UCH; ++i) {
+                const int k = (i * 64 + lane) * 4;
+                if (k < d) {
+                    const float4 w4 = ld4(p.fold_lnw + k), b4 = ld4(p.fold_lnb + k);
+                    float4 y;
+                    y.x = (uv[i].x - mean) * rstd * w4.x + b4.x; y.y = (uv[i].y - mean) * rstd * w4.y + b4.y;
+                    y.z = (uv[i].z - mean) * rstd * w4.z + b4.z; y.w = (uv[i].w - mean) * rstd * w4.w + b4.w;
+                    st4(p.xn + (size_t)b * d + k, y);
+                }
+            }
+        }
+    }
+    constexpr bool fresh = FOLD == 2;             // key/value of position t live in registers, not in the cache
+    const int n_keys = fresh ? t : t + 1;
     const float* eb = RPR ? p.Er + (size_t)(p.er_len - 1 - t) * HD + c * 4 : nullptr;   // Er row of key 0
+    if (fresh && wave == 0 && sub == 0) {
+        st4(p.k_new + (((size_t)b * p.H + h) * p.cap + t) * HD + c * 4, kn4);
+        st4(p.v_new + (((size_t)b * p.H + h) * p.cap + t) * HD + c * 4, vn4);
+    }
     if (RPR) load_er<HD>(b0, eb, j0, sub, n_keys);
     float m = -INFINITY, l = 0.f;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -115,6 +183,23 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnDecodeParams p
         if (j0 + STRIDE < n_keys) load_batch<HD, RPR, NT>(b0, kb, vb, eb, j0 + STRIDE, sub, n_keys);
         consume_batch<HD, RPR>(b1, q4, j0, sub, n_keys, m, l, o);
         j0 += STRIDE;
+    }
+    if (fresh && wave == 0) {                        // the current position's own key (relative distance 0)
+        float4 k4 = kn4;
+        if (RPR) {
+            const float4 e = ld4(p.Er + (size_t)(p.er_len - 1) * HD + c * 4);
+            k4.x += e.x; k4.y += e.y; k4.z += e.z; k4.w += e.w;
+        }
+        float s = q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
+        s = group_sum<LPK>(s);
+        if (sub == 0) {
+            const float mn = fmaxf(m, s);
+            const float alpha = __expf(m - mn), pj = __expf(s - mn);
+            l = l * alpha + pj;
+            o.x = o.x * alpha + pj * vn4.x; o.y = o.y * alpha + pj * vn4.y;
+            o.z = o.z * alpha + pj * vn4.z; o.w = o.w * alpha + pj * vn4.w;
+            m = mn;
+        }
     }
 
     // merge the KPW lane groups of the wave (lanes with equal c)
@@ -156,20 +241,20 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnDecodeParams p
     }
 }
 
-template <int HD>
+template <int HD, int FOLD>
 void launch_decode(const AttnDecodeParams& p, hipStream_t stream) {
     dim3 grid(p.H, p.B);
     // K/V are streamed once per launch and exceed the 256 MiB Infinity Cache per step: non-temporal loads keep
-    // the step's re-used bytes (63 MB of weights, activations) resident instead (measured +8 % tokens/s at
+    // the step's re-used bytes (weights, activations) resident instead (measured +8 % tokens/s at
     // config 2).  AMT_NT overrides for experiments: bit 0 = self-attention, bit 1 = cross-attention.
     static int nt_mask = -1;
     if (nt_mask < 0) { const char* e = getenv("AMT_NT"); nt_mask = e ? atoi(e) : 3; }
     if (p.Er) {
-        if (nt_mask & 1) hipLaunchKernelGGL((attn_decode_kernel<HD, true, true>), grid, dim3(NW * 64), 0, stream, p);
-        else hipLaunchKernelGGL((attn_decode_kernel<HD, true, false>), grid, dim3(NW * 64), 0, stream, p);
+        if (nt_mask & 1) hipLaunchKernelGGL((attn_decode_kernel<HD, true, true, FOLD>), grid, dim3(NW * 64), 0, stream, p);
+        else hipLaunchKernelGGL((attn_decode_kernel<HD, true, false, FOLD>), grid, dim3(NW * 64), 0, stream, p);
     } else {
-        if (nt_mask & 2) hipLaunchKernelGGL((attn_decode_kernel<HD, false, true>), grid, dim3(NW * 64), 0, stream, p);
-        else hipLaunchKernelGGL((attn_decode_kernel<HD, false, false>), grid, dim3(NW * 64), 0, stream, p);
+        if (nt_mask & 2) hipLaunchKernelGGL((attn_decode_kernel<HD, false, true, FOLD>), grid, dim3(NW * 64), 0, stream, p);
+        else hipLaunchKernelGGL((attn_decode_kernel<HD, false, false, FOLD>), grid, dim3(NW * 64), 0, stream, p);
     }
 }
 
@@ -179,12 +264,36 @@ int32_t amt_launch_attn_decode(const AttnDecodeParams& p, hipStream_t stream) {
     AMT_CHECK_ARG(p.B > 0 && p.H > 0 && p.cap > 0, "attn_decode: bad shape B=%d H=%d cap=%d", p.B, p.H, p.cap);
     AMT_CHECK_ARG(p.pos != nullptr || (p.n_keys > 0 && p.n_keys <= p.cap), "attn_decode: n_keys=%d outside (0,%d]", p.n_keys, p.cap);
     AMT_CHECK_ARG(p.Er == nullptr || p.er_len >= p.cap, "attn_decode: er_len=%d smaller than the key capacity %d", p.er_len, p.cap);
-    switch (p.hd) {
-        case 16: launch_decode<16>(p, stream); break;
-        case 32: launch_decode<32>(p, stream); break;
-        case 64: launch_decode<64>(p, stream); break;
-        case 128: launch_decode<128>(p, stream); break;
-        default: AMT_CHECK_ARG(false, "attn_decode: head_dim %d not in {16,32,64,128}", p.hd);
+    if (p.fold_u) {
+        AMT_CHECK_ARG(p.fold_g && p.fold_c && p.d == p.H * p.hd && p.d % 4 == 0 && p.d <= UCH * 256 && p.ldq >= p.d && p.ldq % 4 == 0,
+                      "attn_decode: bad folded prologue (d=%d ldq=%d)", p.d, p.ldq);
+        AMT_CHECK_ARG(!p.xn || (p.fold_lnw && p.fold_lnb), "attn_decode: xn needs the LayerNorm affine");
+        AMT_CHECK_ARG(!p.new_kv || (p.pos && p.k_new && p.v_new && p.ldq >= 3 * p.d), "attn_decode: new_kv needs pos, the cache and 3d raw columns");
+        if (p.new_kv) {
+            switch (p.hd) {
+                case 16: launch_decode<16, 2>(p, stream); break;
+                case 32: launch_decode<32, 2>(p, stream); break;
+                case 64: launch_decode<64, 2>(p, stream); break;
+                case 128: launch_decode<128, 2>(p, stream); break;
+                default: AMT_CHECK_ARG(false, "attn_decode: head_dim %d not in {16,32,64,128}", p.hd);
+            }
+        } else {
+            switch (p.hd) {
+                case 16: launch_decode<16, 1>(p, stream); break;
+                case 32: launch_decode<32, 1>(p, stream); break;
+                case 64: launch_decode<64, 1>(p, stream); break;
+                case 128: launch_decode<128, 1>(p, stream); break;
+                default: AMT_CHECK_ARG(false, "attn_decode: head_dim %d not in {16,32,64,128}", p.hd);
+            }
+        }
+    } else {
+        switch (p.hd) {
+            case 16: launch_decode<16, 0>(p, stream); break;
+            case 32: launch_decode<32, 0>(p, stream); break;
+            case 64: launch_decode<64, 0>(p, stream); break;
+            case 128: launch_decode<128, 0>(p, stream); break;
+            default: AMT_CHECK_ARG(false, "attn_decode: head_dim %d not in {16,32,64,128}", p.hd);
+        }
     }
     AMT_LAUNCH_CHECK();
     return 0;

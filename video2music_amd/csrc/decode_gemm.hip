@@ -21,7 +21,6 @@ namespace {
 
 constexpr int MAXB = 32;
 constexpr int XPAD = 8;
-constexpr int MAX_TPW = 4;      // k-tiles per wave (16 waves): K <= 1024
 
 __global__ void pack_weight_kernel(const float* __restrict__ W, float* __restrict__ P, int N, int K) {
     const int kt_n = K / 16;
@@ -37,8 +36,22 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, float* __restric
 constexpr int NW = 16;           // waves per workgroup: K is split 16 ways, one staged row per wave
 constexpr int MT = 16;           // rows per workgroup (one MFMA row block); blockIdx.y selects the block
 
-// KCH = float4 chunks per lane and row (K <= KCH*256); FULL: K == KCH*256, no lane predicates
-template <int KCH, bool FULL>
+__device__ __forceinline__ float sum4(const float4 a) { return (a.x + a.y) + (a.z + a.w); }
+__device__ __forceinline__ float sq4(const float4 a, float m) {
+    const float dx = a.x - m, dy = a.y - m, dz = a.z - m, dw = a.w - m;
+    return (dx * dx + dy * dy) + (dz * dz + dw * dw);
+}
+
+// KCH = float4 chunks per lane and row (K <= KCH*256) = weight tiles per wave; FULL: K == KCH*256, no lane
+// predicates; PRO: 0 plain rows, 1 LayerNorm prologue, 2 folded-FFN prologue.
+//
+// Everything the kernel reads from global memory is issued up front in ONE branch-free sequence: rows, prologue
+// vectors, weight tiles, epilogue operands (out-of-range lanes read a clamped address and discard the value).
+// Vector loads return in issue order and the compiler can only count them across straight-line code: with the
+// rows first and no branch in between, the prologue waits for the (L2-resident) rows alone while the weight tiles
+// (Infinity Cache / HBM) are still in flight.  A conditional load anywhere in that sequence degrades every later
+// wait to vmcnt(0), i.e. serialises the prologue behind the weights.
+template <int KCH, bool FULL, int PRO>
 __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = p.K, LD = K + XPAD;
@@ -46,91 +59,138 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
     float* red = smem;                              // [16 waves][4 r][64 lanes], reuses xs after the MFMA phase
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, m0 = blockIdx.y * MT;
-    const int kt_n = K / 16, tpw = (kt_n + NW - 1) / NW;
+    // column split: tiles below n_split multiply the first K1 input columns by Wp, the others all K by Wp2
+    const int nts = p.n_split >> 4;
+    const bool high = p.n_split > 0 && nt >= nts;
+    const int K1 = p.x2 ? p.K1 : K;                 // first column taken from x2
+    const int Kw = (p.n_split > 0 && !high) ? p.K1 : K;
+    const int kt_n = Kw / 16, tpw = (kt_n + NW - 1) / NW;
     const int kt0 = wave * tpw;
 
-    // ---- issue this wave's weight tile loads first: they do not depend on the prologue ----
-    float4 wt[MAX_TPW];
-    const float* wp = p.Wp + (((size_t)nt * kt_n + (size_t)kt0) * 64 + lane) * 4;
-#pragma unroll
-    for (int i = 0; i < MAX_TPW; ++i)
-        if (i < tpw && kt0 + i < kt_n) wt[i] = (p.dbg & 1) ? make_float4(1.f, 1.f, 1.f, 1.f) : ld4(wp + (size_t)i * 256);
-
-    // ---- prologue: wave w stages (normalised) row m0+w into LDS ----
-    const int r = m0 + wave;
+    // ---- 1. the row this wave stages: row m0+wave (clamped; rows >= B are zeroed when stored) ----
+    const int r = m0 + wave, rc = min(r, p.B - 1);
+    const float* xr = p.x + (size_t)rc * p.ldx;
+    const float* x2r = p.x2 ? p.x2 + (size_t)rc * p.ldx2 - K1 : xr;
     float4 v[KCH];
 #pragma unroll
     for (int c = 0; c < KCH; ++c) {
-        const int i = (c * 64 + lane) * 4;
-        v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((FULL || i < K) && r < p.B && !(p.dbg & 2)) v[c] = ld4(p.x + (size_t)r * p.ldx + i);
+        const int i = (c * 64 + lane) * 4, ic = FULL ? i : min(i, K - 4);
+        v[c] = ld4((ic < K1 ? xr : x2r) + ic);
     }
-    // epilogue operands do not depend on anything computed here: fetch them now
+    // ---- 2. prologue vectors ----
+    float4 g0[PRO == 1 ? KCH : 1], h0[PRO == 1 ? KCH : 1];
+    if (PRO == 1) {
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            const int i = (c * 64 + lane) * 4, ic = FULL ? i : min(i, K - 4);
+            g0[c] = ld4(p.ln_w + ic);
+            h0[c] = ld4(p.ln_b + ic);
+        }
+    }
+    // folded FFN: the per-column vectors (same for all 16 rows) go through LDS, one float4 per thread (K/2 <= 1024)
+    float4 gs_val = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int gs_t = min(tid, K / 2 - 1), gs_vec = gs_t >= K / 4, gs_i = (gs_t - gs_vec * (K / 4)) * 4;
+    if (PRO == 2) {
+        const float* a = gs_i < K1 ? p.fold_g + gs_i : p.ln_w + (gs_i - K1);
+        const float* b = gs_i < K1 ? p.fold_c + gs_i : p.ln_b + (gs_i - K1);
+        gs_val = ld4(gs_vec ? b : a);
+    }
+    // ---- 3. this wave's weight tiles (tile index clamped: surplus loads repeat the last tile) ----
+    float4 wt[KCH];
+    const float* wbase = high ? p.Wp2 + (size_t)(nt - nts) * kt_n * 256 : p.Wp + (size_t)nt * kt_n * 256;
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) wt[i] = ld4(wbase + ((size_t)min(kt0 + i, kt_n - 1) * 64 + lane) * 4);
+    // ---- 4. epilogue operands ----
     const int el = tid & 63, er = (tid >> 6) & 3;
     const int row = m0 + 4 * (el >> 4) + er, n = nt * 16 + (el & 15);
-    const bool live = tid < 256 && row < p.B && n < p.N && !(p.dbg & 32);
-    float e_bias = 0.f, e_res = 0.f;
-    int t = 0;
-    if (live) {
-        if (p.bias) e_bias = p.bias[n];
-        if (p.mode == 0 && p.resid) e_res = p.resid[(size_t)row * p.ldr + n];
-        if (p.pos) t = *p.pos;
-    }
-    if (p.ln_w && !(p.dbg & 4)) {
-        const float inv_k = 1.0f / (float)K;
+    const bool live = tid < 256 && row < p.B && n < p.N;
+    const float* bp = high ? p.bias2 : p.bias;
+    const bool has_b = live && bp != nullptr, has_r = live && !high && p.mode == 0 && p.resid != nullptr;
+    float e_bias = *(has_b ? bp + (high ? n - p.n_split : n) : p.Wp);
+    float e_res = *(has_r ? p.resid + (size_t)row * p.ldr + n : p.Wp);
+    const int t = *(p.pos ? p.pos : reinterpret_cast<const int*>(p.Wp));
+    if (!has_b) e_bias = 0.f;
+    if (!has_r) e_res = 0.f;
+
+    // ---- prologue math ----
+    if (PRO == 2) {
+        // [ relu((raw - mu*g)*rstd + c) | LayerNorm(u) ], statistics over the u half (columns K1..K-1)
+        float* gs = smem + MT * LD;                 // [2][K]: g|gamma , c|beta
+        if (tid < K / 2) st4(gs + gs_vec * K + gs_i, gs_val);
+        const float inv_n = 1.0f / (float)(K - K1);
+        float s = 0.f;
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            const float* gw = pass == 0 ? p.ln_w : p.ln2_w;
-            const float* gb = pass == 0 ? p.ln_b : p.ln2_b;
-            if (!gw) break;
-            float4 g[KCH], h[KCH];
+        for (int c = 0; c < KCH; ++c) {
+            const int i = (c * 64 + lane) * 4;
+            if (i >= K1 && (FULL || i < K)) s += sum4(v[c]);
+        }
+        const float mean = wave_sum(s) * inv_n;
+        float q = 0.f;
 #pragma unroll
-            for (int c = 0; c < KCH; ++c) {
-                const int i = (c * 64 + lane) * 4;
-                g[c] = (FULL || i < K) ? ld4(gw + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-                h[c] = (FULL || i < K) ? ld4(gb + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            float s = 0.f;
+        for (int c = 0; c < KCH; ++c) {
+            const int i = (c * 64 + lane) * 4;
+            if (i >= K1 && (FULL || i < K)) q += sq4(v[c], mean);
+        }
+        const float rstd = rsqrtf(wave_sum(q) * inv_n + p.eps);
+        __syncthreads();
 #pragma unroll
-            for (int c = 0; c < KCH; ++c) s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
-            const float mean = wave_sum(s) * inv_k;
-            float q = 0.f;
-#pragma unroll
-            for (int c = 0; c < KCH; ++c) {
-                const int i = (c * 64 + lane) * 4;
-                if (FULL || i < K) {
-                    const float dx = v[c].x - mean, dy = v[c].y - mean, dz = v[c].z - mean, dw = v[c].w - mean;
-                    q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        for (int c = 0; c < KCH; ++c) {
+            const int i = (c * 64 + lane) * 4;
+            if (FULL || i < K) {
+                const float4 g = ld4(gs + i), h = ld4(gs + K + i);
+                if (i < K1) {
+                    v[c].x = fmaxf((v[c].x - mean * g.x) * rstd + h.x, 0.f); v[c].y = fmaxf((v[c].y - mean * g.y) * rstd + h.y, 0.f);
+                    v[c].z = fmaxf((v[c].z - mean * g.z) * rstd + h.z, 0.f); v[c].w = fmaxf((v[c].w - mean * g.w) * rstd + h.w, 0.f);
+                } else {
+                    v[c].x = (v[c].x - mean) * rstd * g.x + h.x; v[c].y = (v[c].y - mean) * rstd * g.y + h.y;
+                    v[c].z = (v[c].z - mean) * rstd * g.z + h.z; v[c].w = (v[c].w - mean) * rstd * g.w + h.w;
                 }
             }
-            const float rstd = rsqrtf(wave_sum(q) * inv_k + p.eps);
+        }
+    } else if (PRO == 1) {
+        const float inv_k = 1.0f / (float)K;
+        float s = 0.f;
 #pragma unroll
-            for (int c = 0; c < KCH; ++c) {
-                v[c].x = (v[c].x - mean) * rstd * g[c].x + h[c].x; v[c].y = (v[c].y - mean) * rstd * g[c].y + h[c].y;
-                v[c].z = (v[c].z - mean) * rstd * g[c].z + h[c].z; v[c].w = (v[c].w - mean) * rstd * g[c].w + h[c].w;
-            }
+        for (int c = 0; c < KCH; ++c) {
+            const int i = (c * 64 + lane) * 4;
+            if (FULL || i < K) s += sum4(v[c]);
+        }
+        const float mean = wave_sum(s) * inv_k;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            const int i = (c * 64 + lane) * 4;
+            if (FULL || i < K) q += sq4(v[c], mean);
+        }
+        const float rstd = rsqrtf(wave_sum(q) * inv_k + p.eps);
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            v[c].x = (v[c].x - mean) * rstd * g0[c].x + h0[c].x; v[c].y = (v[c].y - mean) * rstd * g0[c].y + h0[c].y;
+            v[c].z = (v[c].z - mean) * rstd * g0[c].z + h0[c].z; v[c].w = (v[c].w - mean) * rstd * g0[c].w + h0[c].w;
         }
     }
 #pragma unroll
     for (int c = 0; c < KCH; ++c) {
         const int i = (c * 64 + lane) * 4;
-        if ((FULL || i < K) && !(p.dbg & 16)) st4(xs + wave * LD + i, (r < p.B) ? v[c] : make_float4(0.f, 0.f, 0.f, 0.f));
+        if (FULL || i < K) st4(xs + wave * LD + i, (r < p.B) ? v[c] : make_float4(0.f, 0.f, 0.f, 0.f));
     }
     __syncthreads();
 
     // the normalised rows are the residual of the following block: workgroup (nt, m-block) publishes its
     // 16 rows x columns 16nt..16nt+15
-    if (p.ln_w && p.xn && nt * 16 < K && tid < 256) {
+    if (PRO == 1 && p.xn && nt * 16 < K && tid < 256) {
         const int rr = tid >> 4, c = tid & 15;
         if (m0 + rr < p.B) p.xn[(size_t)(m0 + rr) * K + nt * 16 + c] = xs[rr * LD + nt * 16 + c];
     }
+    // folded FFN: the LayerNorm half of the staged row is the residual of the low columns
+    if (PRO == 2 && live && !high) e_res = xs[(row - m0) * LD + K1 + n];
 
     // ---- main: 4 MFMAs per k-tile ----
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const float* xa = xs + (lane & 15) * LD + kt0 * 16 + 4 * (lane >> 4);
 #pragma unroll
-    for (int i = 0; i < MAX_TPW; ++i) {
-        if (i < tpw && kt0 + i < kt_n && !(p.dbg & 8)) {
+    for (int i = 0; i < KCH; ++i) {
+        if (i < tpw && kt0 + i < kt_n) {
             const float4 a0 = ld4(xa + i * 16);
             const float4 w = wt[i];
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w.x, acc, 0, 0, 0);
@@ -150,31 +210,42 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
 #pragma unroll
         for (int w = 0; w < NW; ++w) val += red[w * 256 + tid];
         val += e_bias;
-        if (n < p.scale_cols) val *= p.scale;
-        if (p.mode == 0) {
-            val += e_res;
-            if (p.relu) val = fmaxf(val, 0.f);
-            p.y[(size_t)row * p.ldy + n] = val;
-        } else if (n < p.d) {
-            p.y[(size_t)row * p.ldy + n] = val;
+        if (high) {
+            p.y2[(size_t)row * p.ldy2 + (n - p.n_split)] = val;
         } else {
-            const int nn = (n < 2 * p.d) ? n - p.d : n - 2 * p.d;
-            const int hh = nn / p.hd, cc = nn - hh * p.hd;
-            float* dst = (n < 2 * p.d) ? p.kcache : p.vcache;
-            dst[(((size_t)row * p.H + hh) * p.cap + t) * p.hd + cc] = val;
+            if (n < p.scale_cols) val *= p.scale;
+            if (p.mode == 0) {
+                val += e_res;
+                if (p.relu) val = fmaxf(val, 0.f);
+                p.y[(size_t)row * p.ldy + n] = val;
+            } else if (n < p.d) {
+                p.y[(size_t)row * p.ldy + n] = val;
+            } else {
+                const int nn = (n < 2 * p.d) ? n - p.d : n - 2 * p.d;
+                const int hh = nn / p.hd, cc = nn - hh * p.hd;
+                float* dst = (n < 2 * p.d) ? p.kcache : p.vcache;
+                dst[(((size_t)row * p.H + hh) * p.cap + t) * p.hd + cc] = val;
+            }
         }
     }
 }
 
-template <int KCH, bool FULL>
-int32_t launch_variant(const DecodeGemmParams& p, size_t lds, hipStream_t stream) {
+template <int KCH, bool FULL, int PRO>
+int32_t launch_one(const DecodeGemmParams& p, size_t lds, hipStream_t stream) {
     static bool attr_set = false;        // > 64 KiB of dynamic LDS needs the opt-in (gfx950: 160 KiB per CU)
     if (!attr_set) {
-        AMT_HIP(hipFuncSetAttribute((const void*)decode_gemm_kernel<KCH, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        AMT_HIP(hipFuncSetAttribute((const void*)decode_gemm_kernel<KCH, FULL, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((decode_gemm_kernel<KCH, FULL>), dim3(cdiv(p.N, 16), cdiv(p.B, MT)), dim3(NW * 64), lds, stream, p);
+    hipLaunchKernelGGL((decode_gemm_kernel<KCH, FULL, PRO>), dim3(cdiv(p.N, 16), cdiv(p.B, MT)), dim3(NW * 64), lds, stream, p);
     return 0;
+}
+
+template <int KCH, bool FULL>
+int32_t launch_variant(const DecodeGemmParams& p, size_t lds, hipStream_t stream) {
+    if (p.pro == 1) return launch_one<KCH, FULL, 2>(p, lds, stream);
+    if (p.ln_w) { if constexpr (KCH <= 4) return launch_one<KCH, FULL, 1>(p, lds, stream); }
+    return launch_one<KCH, FULL, 0>(p, lds, stream);
 }
 
 }  // namespace
@@ -189,20 +260,30 @@ int32_t amt_launch_pack_weight(const float* W, float* P, int N, int K, hipStream
 
 int32_t amt_launch_decode_gemm(const DecodeGemmParams& p, hipStream_t stream) {
     AMT_CHECK_ARG(p.B > 0 && p.B <= MAXB, "decode_gemm: B=%d outside (0,%d]", p.B, MAXB);
-    AMT_CHECK_ARG(p.K % 64 == 0 && p.K <= 1024, "decode_gemm: K=%d must be a multiple of 64 and <= 1024", p.K);
-    AMT_CHECK_ARG(p.N > 0 && p.ldx >= p.K && p.ldx % 4 == 0, "decode_gemm: bad N/ldx");
+    AMT_CHECK_ARG(p.K % 64 == 0 && p.K <= 1536, "decode_gemm: K=%d must be a multiple of 64 and <= 1536", p.K);
+    AMT_CHECK_ARG(p.N > 0 && p.ldx % 4 == 0, "decode_gemm: bad N/ldx");
     AMT_CHECK_ARG(p.mode == 0 || (p.kcache && p.vcache && p.d > 0 && p.N == 3 * p.d && p.d == p.H * p.hd), "decode_gemm: bad QKV epilogue");
+    if (p.x2) AMT_CHECK_ARG(p.K1 > 0 && p.K1 < p.K && p.K1 % 16 == 0 && p.ldx >= p.K1 && p.ldx2 >= p.K - p.K1 && p.ldx2 % 4 == 0,
+                            "decode_gemm: bad two-source split K1=%d of K=%d", p.K1, p.K);
+    else AMT_CHECK_ARG(p.ldx >= p.K, "decode_gemm: ldx=%d < K=%d", p.ldx, p.K);
+    if (p.n_split) AMT_CHECK_ARG(p.x2 && p.n_split % 16 == 0 && p.n_split <= p.N && p.mode == 0 && (p.n_split == p.N || (p.Wp2 && p.y2)),
+                                 "decode_gemm: bad column split %d of N=%d", p.n_split, p.N);
+    if (p.pro == 1) AMT_CHECK_ARG(p.x2 && p.fold_g && p.fold_c && p.ln_w && p.ln_b && !p.resid, "decode_gemm: incomplete folded-FFN prologue");
+    else AMT_CHECK_ARG(!p.ln_w || (!p.x2 && p.K <= 1024), "decode_gemm: the LayerNorm prologue takes a single source of K <= 1024");
     size_t lds = (size_t)MT * (p.K + XPAD) * sizeof(float);
     if (lds < (size_t)NW * 256 * sizeof(float)) lds = (size_t)NW * 256 * sizeof(float);
+    if (p.pro == 1) lds += (size_t)2 * p.K * sizeof(float);
     int32_t rc;
     switch (p.K) {
         case 256: rc = launch_variant<1, true>(p, lds, stream); break;
         case 512: rc = launch_variant<2, true>(p, lds, stream); break;
         case 768: rc = launch_variant<3, true>(p, lds, stream); break;
         case 1024: rc = launch_variant<4, true>(p, lds, stream); break;
+        case 1536: rc = launch_variant<6, true>(p, lds, stream); break;
         default:
             if (p.K < 256) rc = launch_variant<1, false>(p, lds, stream);
-            else rc = launch_variant<4, false>(p, lds, stream);
+            else if (p.K < 1024) rc = launch_variant<4, false>(p, lds, stream);
+            else rc = launch_variant<6, false>(p, lds, stream);
     }
     if (rc) return rc;
     AMT_LAUNCH_CHECK();

@@ -71,6 +71,15 @@ struct AttnDecodeParams {
     const int* pos;             // device: index of the query token (keys 0..pos); null -> n_keys fixed
     int n_keys;                 // used when pos == null (cross-attention: S)
     const float* Er; int er_len;
+    // Folded-LayerNorm prologue (fold_u != null).  The producing GEMM ran on the *un-normalised* sum u and left
+    // raw = u . (W o gamma)^T in q (row stride ldq; the head's query at column h*hd, and for self-attention its new
+    // key / value at d + h*hd and 2d + h*hd).  With the row statistics (mu, rstd) of u[b] the projection of
+    // LayerNorm(u) is  (raw - mu*fold_g) * rstd + fold_c ; the query is then multiplied by q_scale.  Head 0 also
+    // publishes LayerNorm(u[b]) to xn (the residual of the following block).  new_kv: the key/value of position
+    // *pos come from the prologue (and are written to the cache here); the cache holds keys 0..pos-1 only.
+    const float* fold_u; const float* fold_g; const float* fold_c; const float* fold_lnw; const float* fold_lnb;
+    float* xn; int ldq, d, new_kv; float eps, q_scale;
+    float* k_new; float* v_new;   // the (writable) cache when new_kv
 };
 int32_t amt_launch_attn_decode(const AttnDecodeParams& p, hipStream_t stream);
 
@@ -92,9 +101,27 @@ struct DecodeGemmParams {
     float* y; int ldy;
     // mode 1
     float* kcache; float* vcache; int H, hd, cap; const int* pos; int d;
+    // Two-source input rows: columns [0,K1) come from x, [K1,K) from x2 (K1 == 0 or K: single source)
+    const float* x2; int ldx2, K1;
+    // pro == 1 (FFN-down with LayerNorm folded through FFN-up): x holds raw = u . (W1 o gamma)^T [B][K1], x2 the
+    // pre-LN sum u [B][K-K1]; the staged row is [ relu((raw - mu*fold_g)*rstd + fold_c) | LayerNorm(u) ] with
+    // (mu, rstd) the statistics of u's row; ln_w / ln_b are that LayerNorm's affine.  The LayerNorm half is also
+    // the residual of the columns below n_split.
+    int pro; const float* fold_g; const float* fold_c;
+    // Column split: output columns [0,n_split) use the packed weight Wp over the first K1 input columns only
+    // (bias, residual, ReLU as in mode 0) and go to y; columns [n_split,N) use Wp2 over all K columns, get
+    // bias2[n - n_split] only and go to y2[row*ldy2 + n - n_split].  n_split == 0: no split.
+    const float* Wp2; const float* bias2; float* y2; int ldy2, n_split;
     int dbg;                    // micro-benchmark ablation mask (0 in production): 1 no weight loads, 2 no x loads, 4 no LN, 8 no MFMA, 16 no LDS staging, 32 no epilogue
 };
 int32_t amt_launch_decode_gemm(const DecodeGemmParams& p, hipStream_t stream);
+
+// ---------------- load-time LayerNorm folding (fold.hip) ----------------
+int32_t amt_launch_scale_cols(const float* W, const float* gamma, float* out, int N, int K, hipStream_t stream);   // out = W o gamma
+int32_t amt_launch_transpose(const float* in, float* out, int R, int C, hipStream_t stream);                     // [R][C] -> [C][R]
+// g[n] = sum_k Ws[n][k] ; c[n] = W[n].beta + b[n] ; dv[n] = Ws[n].bo   (fp64 accumulation)
+int32_t amt_launch_fold_vectors(const float* W, const float* Ws, const float* beta, const float* b, const float* bo,
+                                float* g, float* c, float* dv, int N, int K, hipStream_t stream);
 
 // ---------------- sampling head (sample.hip) ----------------
 struct SampleParams {
