@@ -118,14 +118,14 @@ def roofline(model, f, prim, B, T, cfg):
     if os.path.exists(pmc) and cfg["d_model"] == 512:
         traffic = round(json.load(open(pmc))["self_attn"]["traffic_over_algorithmic"] * st["self_attn_decode"]["bytes"] / n)
     return {
-        "bound": "hbm", "kernel": "attn_decode_kernel<64, true> (relative-position self-attention, decode step)",
+        "bound": "hbm", "kernel": "attn_decode_kernel<64, true, true, {0,2}> (relative-position self-attention, decode step; FOLD 2 in layers 1-5)",
         "achieved": round(gbs("self_attn_decode"), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(gbs("self_attn_decode") / HBM_PEAK_GBS, 4), "traffic": traffic,
         "launches": n, "avg_launch_us": round(avg_us("self_attn_decode"), 3),
         "algorithmic_bytes_per_launch": round(st["self_attn_decode"]["bytes"] / n),
         "measured": "HIP event pair on the launch stream around every launch of an eager replay of one full generate, "
                     f"minus the empty-pair cost ({empty_us:.2f} us)",
-        "second_kernel": {"kernel": "attn_decode_kernel<64, false> (cross-attention over video K/V, decode step)",
+        "second_kernel": {"kernel": "attn_decode_kernel<64, false, true, 1> (cross-attention over video K/V, decode step)",
                           "achieved": round(gbs("cross_attn_decode"), 1), "frac": round(gbs("cross_attn_decode") / HBM_PEAK_GBS, 4),
                           "avg_launch_us": round(avg_us("cross_attn_decode"), 3),
                           "algorithmic_bytes_per_launch": round(st["cross_attn_decode"]["bytes"] / n)},

@@ -113,6 +113,25 @@ def test_generate_batch_equals_single_and_decode_logits_match_forward(model1):
     assert err < 2e-4, err
 
 
+def test_folded_and_plain_decode_chains_agree(monkeypatch):
+    """The shipped decode chain folds every LayerNorm through the next projection (32 launches per step); the plain
+    chain (49 launches, `AMT_DECODE_CHAIN=plain`, also the fallback for shapes the fold does not cover) must give
+    the same ids and logits up to fp32 rounding."""
+    feats = synthetic.synthetic_features(4, seed=99)
+    f = cu(feats_t(feats))
+    pr, prr, pra = (torch.tensor([v]) for v in C.primer_from_name("A:min"))
+    out = {}
+    for chain in ("folded", "plain"):
+        if chain == "plain":
+            monkeypatch.setenv("AMT_DECODE_CHAIN", "plain")     # read when the handle is finalized
+        m, sd = build(CFG1, seed=3)
+        out[chain] = m.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], pr, prr, pra,
+                                      target_seq_length=120, beam=0, sampler="argmax", return_logits=True)
+    assert torch.equal(out["folded"][0], out["plain"][0])
+    err = (out["folded"][1][:119] - out["plain"][1][:119]).abs().max().item()
+    assert 0 < err < 1e-4, err        # > 0: the two chains really are different arithmetic
+
+
 def test_sampled_generate_is_valid_and_seeded(model1):
     m, _ = model1
     f = cu(feats_t(synthetic.synthetic_features(2, seed=5)))

@@ -485,6 +485,7 @@ extern "C" int32_t amt_finalize(amt_handle* h) {
     if ((rc = need(h, "positional_encoding.pe", {h->Tcap, 1, d}, &h->pe))) return rc;
     if ((rc = need(h, "positional_encoding_video.pe", {h->Scap, 1, d}, &h->pe_v))) return rc;
 
+    if ((rc = amt_decode_gemm_init())) return rc;
     if ((int)h->enc.size() != h->nl) h->enc.assign(h->nl, EncLayer{});
     if ((int)h->dec.size() != h->nl) h->dec.assign(h->nl, DecLayer{});      // keeps the packed buffers across re-finalize
     for (int l = 0; l < h->nl; ++l) {
@@ -960,7 +961,7 @@ extern "C" int32_t amt_decode_linear_fwd(const float* x, const float* w, const f
     AMT_CHECK_ARG(x && w && y && w_packed_scratch, "amt_decode_linear_fwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     int dbg = 0;
-    if (const char* e = getenv("AMT_DBG")) dbg = atoi(e);          // micro-benchmark ablations only
+    if (const char* e = getenv("AMT_DBG")) dbg = atoi(e);          // micro-benchmarks only
     if (!(dbg & 16)) {                                             // 16: scratch already holds the packed weight
         int32_t rc = amt_launch_pack_weight(w, w_packed_scratch, N, K, s);
         if (rc) return rc;
@@ -969,6 +970,5 @@ extern "C" int32_t amt_decode_linear_fwd(const float* x, const float* w, const f
     g.x = x; g.ldx = K; g.Wp = w_packed_scratch; g.bias = bias; g.B = B; g.N = N; g.K = K;
     g.ln_w = ln_w; g.ln_b = ln_b; g.xn = xn_out; g.eps = eps; g.resid = resid; g.ldr = N; g.relu = relu;
     g.scale = 1.f; g.y = y; g.ldy = N;
-    g.dbg = dbg & 15;
     return amt_launch_decode_gemm(g, s);
 }

@@ -37,9 +37,15 @@ constexpr int NW = 16;           // waves per workgroup: K is split 16 ways, one
 constexpr int MT = 16;           // rows per workgroup (one MFMA row block); blockIdx.y selects the block
 
 __device__ __forceinline__ float sum4(const float4 a) { return (a.x + a.y) + (a.z + a.w); }
+// (the mean is splat into a full register pair: the packed subtract then has no half it does not define, which
+// otherwise picks up a false dependency on whatever load targets the neighbouring register)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float sq4(const float4 a, float m) {
-    const float dx = a.x - m, dy = a.y - m, dz = a.z - m, dw = a.w - m;
-    return (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    const f32x2 mm = {m, m};
+    f32x2 lo = {a.x, a.y}, hi = {a.z, a.w};
+    lo -= mm; hi -= mm;
+    lo *= lo; hi *= hi;
+    return (lo.x + lo.y) + (hi.x + hi.y);
 }
 
 // KCH = float4 chunks per lane and row (K <= KCH*256) = weight tiles per wave; FULL: K == KCH*256, no lane
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
     const int kt_n = Kw / 16, tpw = (kt_n + NW - 1) / NW;
     const int kt0 = wave * tpw;
 
-    // ---- 1. the row this wave stages: row m0+wave (clamped; rows >= B are zeroed when stored) ----
+    // ---- 1. the row this wave stages: row m0+wave (clamped to the last valid row) ----
     const int r = m0 + wave, rc = min(r, p.B - 1);
     const float* xr = p.x + (size_t)rc * p.ldx;
     const float* x2r = p.x2 ? p.x2 + (size_t)rc * p.ldx2 - K1 : xr;
@@ -100,52 +106,44 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
     const float* wbase = high ? p.Wp2 + (size_t)(nt - nts) * kt_n * 256 : p.Wp + (size_t)nt * kt_n * 256;
 #pragma unroll
     for (int i = 0; i < KCH; ++i) wt[i] = ld4(wbase + ((size_t)min(kt0 + i, kt_n - 1) * 64 + lane) * 4);
-    // ---- 4. epilogue operands ----
+    __builtin_amdgcn_sched_barrier(0);              // the scheduler must not sink any of these loads below this point
     const int el = tid & 63, er = (tid >> 6) & 3;
     const int row = m0 + 4 * (el >> 4) + er, n = nt * 16 + (el & 15);
     const bool live = tid < 256 && row < p.B && n < p.N;
-    const float* bp = high ? p.bias2 : p.bias;
-    const bool has_b = live && bp != nullptr, has_r = live && !high && p.mode == 0 && p.resid != nullptr;
-    float e_bias = *(has_b ? bp + (high ? n - p.n_split : n) : p.Wp);
-    float e_res = *(has_r ? p.resid + (size_t)row * p.ldr + n : p.Wp);
-    const int t = *(p.pos ? p.pos : reinterpret_cast<const int*>(p.Wp));
-    if (!has_b) e_bias = 0.f;
-    if (!has_r) e_res = 0.f;
-
     // ---- prologue math ----
     if (PRO == 2) {
         // [ relu((raw - mu*g)*rstd + c) | LayerNorm(u) ], statistics over the u half (columns K1..K-1)
         float* gs = smem + MT * LD;                 // [2][K]: g|gamma , c|beta
-        if (tid < K / 2) st4(gs + gs_vec * K + gs_i, gs_val);
+        st4(gs + gs_vec * K + gs_i, gs_val);        // unconditional (surplus threads repeat the last float4): a guarded
+                                                    // store lets the compiler sink the load behind the weight loads
         const float inv_n = 1.0f / (float)(K - K1);
-        float s = 0.f;
+        float um[KCH];                              // 1 on the u half, 0 elsewhere (a multiply keeps the loops branch-free)
 #pragma unroll
         for (int c = 0; c < KCH; ++c) {
             const int i = (c * 64 + lane) * 4;
-            if (i >= K1 && (FULL || i < K)) s += sum4(v[c]);
+            um[c] = (i >= K1 && (FULL || i < K)) ? 1.f : 0.f;
         }
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) s += um[c] * sum4(v[c]);
         const float mean = wave_sum(s) * inv_n;
         float q = 0.f;
 #pragma unroll
-        for (int c = 0; c < KCH; ++c) {
-            const int i = (c * 64 + lane) * 4;
-            if (i >= K1 && (FULL || i < K)) q += sq4(v[c], mean);
-        }
+        for (int c = 0; c < KCH; ++c) q += um[c] * sq4(v[c], mean);
         const float rstd = rsqrtf(wave_sum(q) * inv_n + p.eps);
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < KCH; ++c) {
             const int i = (c * 64 + lane) * 4;
-            if (FULL || i < K) {
-                const float4 g = ld4(gs + i), h = ld4(gs + K + i);
-                if (i < K1) {
-                    v[c].x = fmaxf((v[c].x - mean * g.x) * rstd + h.x, 0.f); v[c].y = fmaxf((v[c].y - mean * g.y) * rstd + h.y, 0.f);
-                    v[c].z = fmaxf((v[c].z - mean * g.z) * rstd + h.z, 0.f); v[c].w = fmaxf((v[c].w - mean * g.w) * rstd + h.w, 0.f);
-                } else {
-                    v[c].x = (v[c].x - mean) * rstd * g.x + h.x; v[c].y = (v[c].y - mean) * rstd * g.y + h.y;
-                    v[c].z = (v[c].z - mean) * rstd * g.z + h.z; v[c].w = (v[c].w - mean) * rstd * g.w + h.w;
-                }
-            }
+            // one branch-free form for both halves (x*1.0f is exact): raw half a = mu*g, m = 1, relu; LN half a = mu, m = g
+            const int ic = FULL ? i : min(i, K - 4);
+            const float4 g = ld4(gs + ic), h = ld4(gs + K + ic);
+            const bool rawh = i < K1;
+            const float lo = rawh ? 0.f : -INFINITY;
+            v[c].x = fmaxf((v[c].x - (rawh ? mean * g.x : mean)) * rstd * (rawh ? 1.f : g.x) + h.x, lo);
+            v[c].y = fmaxf((v[c].y - (rawh ? mean * g.y : mean)) * rstd * (rawh ? 1.f : g.y) + h.y, lo);
+            v[c].z = fmaxf((v[c].z - (rawh ? mean * g.z : mean)) * rstd * (rawh ? 1.f : g.z) + h.z, lo);
+            v[c].w = fmaxf((v[c].w - (rawh ? mean * g.w : mean)) * rstd * (rawh ? 1.f : g.w) + h.w, lo);
         }
     } else if (PRO == 1) {
         const float inv_k = 1.0f / (float)K;
@@ -172,9 +170,19 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
 #pragma unroll
     for (int c = 0; c < KCH; ++c) {
         const int i = (c * 64 + lane) * 4;
-        if (FULL || i < K) st4(xs + wave * LD + i, (r < p.B) ? v[c] : make_float4(0.f, 0.f, 0.f, 0.f));
+        if (FULL || i < K) st4(xs + wave * LD + i, v[c]);    // (rows >= B hold a copy of row B-1; their outputs are never stored)
     }
     __syncthreads();
+
+    // ---- 4. epilogue operands: issued behind the prologue so that no register of the prologue's arithmetic sits
+    // next to a pending load (packed VALU ops read register pairs).  Absent operands read a zero word instead of
+    // being masked after the load: a select on a loaded value would be scheduled early and wait for the weights ----
+    const float* bp = high ? p.bias2 : p.bias;
+    const bool has_b = live && bp != nullptr, has_r = PRO != 2 && live && !high && p.mode == 0 && p.resid != nullptr;
+    const float e_bias = *(has_b ? bp + (high ? n - p.n_split : n) : p.zero);
+    float e_res = 0.f;
+    if (PRO != 2) e_res = *(has_r ? p.resid + (size_t)row * p.ldr + n : p.zero);
+    const int t = *(p.pos ? p.pos : reinterpret_cast<const int*>(p.zero));
 
     // the normalised rows are the residual of the following block: workgroup (nt, m-block) publishes its
     // 16 rows x columns 16nt..16nt+15
@@ -258,7 +266,25 @@ int32_t amt_launch_pack_weight(const float* W, float* P, int N, int K, hipStream
     return 0;
 }
 
-int32_t amt_launch_decode_gemm(const DecodeGemmParams& p, hipStream_t stream) {
+// a few zero words in global memory per device (absent bias / residual / position read these)
+static int32_t zero_words(const float** out) {
+    static float* buf[64] = {nullptr};
+    int dev = 0;
+    AMT_HIP(hipGetDevice(&dev));
+    AMT_CHECK_ARG(dev >= 0 && dev < 64, "decode_gemm: device ordinal %d out of range", dev);
+    if (!buf[dev]) {
+        AMT_HIP(hipMalloc((void**)&buf[dev], 256));
+        AMT_HIP(hipMemset(buf[dev], 0, 256));
+    }
+    *out = buf[dev];
+    return 0;
+}
+
+int32_t amt_decode_gemm_init() { const float* z; return zero_words(&z); }
+
+int32_t amt_launch_decode_gemm(const DecodeGemmParams& p_in, hipStream_t stream) {
+    DecodeGemmParams p = p_in;
+    if (int32_t zrc = zero_words(&p.zero)) return zrc;
     AMT_CHECK_ARG(p.B > 0 && p.B <= MAXB, "decode_gemm: B=%d outside (0,%d]", p.B, MAXB);
     AMT_CHECK_ARG(p.K % 64 == 0 && p.K <= 1536, "decode_gemm: K=%d must be a multiple of 64 and <= 1536", p.K);
     AMT_CHECK_ARG(p.N > 0 && p.ldx % 4 == 0, "decode_gemm: bad N/ldx");

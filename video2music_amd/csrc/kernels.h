@@ -91,8 +91,8 @@ struct DecodeGemmParams {
     const float* Wp;            // packed weight
     const float* bias;          // [N]
     int B, N, K;
-    // LayerNorm prologue (optional, up to two stacked LNs); normalised rows are also written to xn (ld = K)
-    const float* ln_w; const float* ln_b; const float* ln2_w; const float* ln2_b; float* xn; float eps;
+    // LayerNorm prologue (optional); normalised rows are also written to xn (ld = K)
+    const float* ln_w; const float* ln_b; float* xn; float eps;
     // epilogue
     int mode;                   // 0: y = acc+bias (+resid) (relu) ; 1: packed-QKV split into q / K-cache / V-cache
     const float* resid; int ldr;
@@ -112,9 +112,11 @@ struct DecodeGemmParams {
     // (bias, residual, ReLU as in mode 0) and go to y; columns [n_split,N) use Wp2 over all K columns, get
     // bias2[n - n_split] only and go to y2[row*ldy2 + n - n_split].  n_split == 0: no split.
     const float* Wp2; const float* bias2; float* y2; int ldy2, n_split;
-    int dbg;                    // micro-benchmark ablation mask (0 in production): 1 no weight loads, 2 no x loads, 4 no LN, 8 no MFMA, 16 no LDS staging, 32 no epilogue
+    const float* zero;          // set by the launcher: zero words in global memory
 };
 int32_t amt_launch_decode_gemm(const DecodeGemmParams& p, hipStream_t stream);
+// allocates the per-device zero words (hipMalloc): call once outside any stream capture
+int32_t amt_decode_gemm_init();
 
 // ---------------- load-time LayerNorm folding (fold.hip) ----------------
 int32_t amt_launch_scale_cols(const float* W, const float* gamma, float* out, int N, int K, hipStream_t stream);   // out = W o gamma
