@@ -103,3 +103,35 @@ def test_rmsnorm_and_rope_modules(golden):
     rope_hd = RotaryPositionalEmbeddings(32, 64).cuda()
     y = rope_hd(torch.from_numpy(g["rope_hd_x"]).cuda())
     assert np.abs(y.cpu().numpy() - g["rope_hd_y"]).max() < 1e-5
+
+
+def test_generate_cli_reads_feature_files_and_writes_lab(tmp_path):
+    """`python -m video2music_amd.generate` on a miniature MuVi-Sync tree: features come
+    from the files, ids go to `<id>_chords.lab`, and the ids equal a direct model.generate on the loaded tensors."""
+    import os
+    from tests.helpers_features import write_mini_dataset, mini_dataset_content
+    from video2music_amd import generate as G, synthetic
+    from video2music_amd.dataset import vevo_features as VF
+    from video2music_amd.model.video_music_transformer import VideoMusicTransformer
+    root, out = str(tmp_path / "data"), str(tmp_path / "out")
+    write_mini_dataset(root, mini_dataset_content(seed=11))
+    argv = ["-dataset_dir", root, "-output_dir", out, "--test_ids", "split:test", "--synthetic_weights", "-music_gen_version", "None",
+            "-n_layers", "2", "-num_heads", "4", "-d_model", "128", "-dim_feedforward", "256", "-target_seq_length_chord", "24",
+            "-max_sequence_chord", "300", "--sampler", "argmax", "-motion_type", "1"]
+    toks = G.main(argv).cpu()
+    assert toks.shape == (2, 24)
+    for i, fid in enumerate(("003", "017")):
+        chord, _, _, _, last = VF.read_chords(os.path.join(out, f"{fid}_chords.lab"), 300)
+        assert last == 23 and chord[:24].tolist() == toks[i].tolist()
+    f = VF.load_clips(root, ["003", "017"], motion_type=1)
+    m = VideoMusicTransformer(n_layers=2, num_heads=4, d_model=128, dim_feedforward=256, max_sequence_chord=300,
+                              total_vf_dim=24 + 1 + 512 + 6, rpr=True).eval()
+    shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=0).items()}, strict=False)
+    m = m.cuda()
+    key = torch.tensor([[VF.key_from_emotion(e)] for e in f["emotion"]])
+    prim = torch.tensor([G.default_primer(k) for k in key[:, 0]])
+    t = lambda k: torch.from_numpy(f[k]).cuda()
+    ref = m.generate_batch(t("semantic"), key.cuda(), t("scene_offset"), t("motion"), t("emotion"), prim[:, 0:1], prim[:, 1:2], prim[:, 2:3],
+                           target_seq_length=24, beam=0, sampler="argmax")
+    assert torch.equal(ref.cpu(), toks)

@@ -3,9 +3,9 @@
 Reproduces the part of the reference script that feeds ``model.generate``: flag names/defaults
 (``parse_generate_args``), the ``total_vf_dim`` rule (:141-160), the batch-1 feature shapes
 (:181-189), the key rule (:199-207), the default primer ("C" / "A:min", :246-284) and the
-``model.generate`` keyword names (:368-392).  Everything after the chord ids (regression model,
-MIDI, FluidSynth, moviepy: :393-709) is out of scope.  Inputs come from ``--synthetic`` or from
-``.npy`` feature files; under torchrun the clips are sharded over ranks and the ids all-gathered.
+``model.generate`` keyword names (:368-392) and the chord ``.lab`` it writes (:440-444).  The rest of what follows
+the chord ids (regression model, MIDI voicing, FluidSynth, moviepy: :393-709) is out of scope.  Inputs come from
+``--synthetic`` or from MuVi-Sync feature files (``-dataset_dir`` + ``--test_ids``, ``dataset/vevo_features.py``); under torchrun the clips are sharded over ranks and the ids all-gathered.
 
     python -m video2music_amd.generate --synthetic --n_clips 4 -target_seq_length_chord 64 -beam 0
 """
@@ -53,22 +53,36 @@ def main(argv=None):
     device = get_device()
     if device.type != "cuda":
         raise SystemExit("no GPU visible: video2music_amd runs on MI355X only")
+    if args.synthetic:
+        feats = synthetic.synthetic_features(args.n_clips, seed=args.seed, n_frames=args.max_sequence_video,
+                                             motion_type=args.motion_type)
+        names = [f"clip{i:03d}" for i in range(args.n_clips)]
+    else:
+        # feature files of the MuVi-Sync layout (dataset/vevo_dataset.py:241-554); key bit by the script's own rule (:199-207)
+        from .dataset import vevo_features as VF
+        if not args.test_ids:
+            raise SystemExit("--test_ids (or --synthetic) is required")
+        names = (VF.read_split(args.dataset_dir, args.test_ids[6:], "v1") if args.test_ids.startswith("split:")
+                 else [t.strip() for t in args.test_ids.split(",") if t.strip()])
+        feats = VF.load_clips(args.dataset_dir, names, vis_models="2d/clip_l14p", emo_model=args.emo_model, motion_type=args.motion_type,
+                              max_seq_video=args.max_sequence_video, max_seq_chord=args.max_sequence_chord)
+        feats["key"] = np.array([[VF.key_from_emotion(e)] for e in feats["emotion"]], dtype=np.float32)
+        feats = {k: feats[k] for k in ("semantic", "key", "scene_offset", "motion", "emotion")}
+        args.n_clips = len(names)
     common = dict(n_layers=args.n_layers, num_heads=args.num_heads, d_model=args.d_model, dim_feedforward=args.dim_feedforward,
                   max_sequence_midi=args.max_sequence_midi, max_sequence_video=args.max_sequence_video,
-                  max_sequence_chord=args.max_sequence_chord, total_vf_dim=total_vf_dim_of(args))
+                  max_sequence_chord=args.max_sequence_chord,
+                  total_vf_dim=total_vf_dim_of(args, sem_dim=feats["semantic"].shape[-1]))     # generate.py:141-143: widths of the loaded features
     if args.music_gen_version is None:                 # generate.py:209-216
         model = VideoMusicTransformer(rpr=args.rpr, **common)
     else:                                              # generate.py:225-230
         model = VideoMusicTransformer_V2(version_name=args.music_gen_version, rms_norm=args.rms_norm, **common)
-    if args.synthetic:
+    if args.synthetic or args.synthetic_weights:
         shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
         sd = {k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=0).items()}
         model.load_state_dict(sd, strict=False)
-        feats = synthetic.synthetic_features(args.n_clips, seed=args.seed, n_frames=args.max_sequence_video,
-                                             motion_type=args.motion_type)
     else:
         model.load_state_dict(torch.load(args.model_weights, map_location="cpu"))
-        raise SystemExit("dataset feature loading (dataset/vevo_dataset.py) is SURVEY.md §8 row f4; use --synthetic")
     model = model.to(device).eval()
     lo, hi = vdist.shard_bounds(args.n_clips, rank, world)
     f = {k: torch.from_numpy(v[lo:hi]).to(device) for k, v in feats.items()}
@@ -95,10 +109,9 @@ def main(argv=None):
     if rank == 0:
         os.makedirs(args.output_dir, exist_ok=True)
         out = toks.cpu().numpy()
-        for i, row in enumerate(out):
-            names = [C.chord_name(int(t)) for t in row]
-            with open(os.path.join(args.output_dir, f"clip{i:03d}_chords.lab"), "w") as fh:
-                fh.write("\n".join(f"{j} {n}" for j, n in enumerate(names)) + "\n")
+        from .dataset.vevo_features import write_lab
+        for name, row in zip(names, out):
+            write_lab(os.path.join(args.output_dir, f"{name}_chords.lab"), row)      # generate.py:440-444
         print(json.dumps({"clips": int(out.shape[0]), "length": int(out.shape[1]), "first": out[0, :16].tolist()}))
     return toks
 

@@ -37,6 +37,10 @@ def parse_generate_args(argv=None):
     # additions of this build
     parser.add_argument("--synthetic", action="store_true", help="random-init procedural weights and random video features")
     parser.add_argument("--n_clips", type=int, default=1, help="clips to generate for (sharded over ranks under torchrun)")
+    parser.add_argument("--test_ids", type=str, default=None,
+                        help="clip ids to read from -dataset_dir, comma separated, or split:<name> for vevo_meta/split/v1/<name>.txt "
+                             "(the reference hard-codes one test_id at generate.py:29)")
+    parser.add_argument("--synthetic_weights", action="store_true", help="random-init procedural weights with real feature files")
     parser.add_argument("--sampler", type=str, default="categorical", choices=["categorical", "argmax"])
     parser.add_argument("--seed", type=int, default=1234)
     return parser.parse_known_args(argv)
