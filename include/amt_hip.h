@@ -189,6 +189,32 @@ int32_t amt_glu_expert_fwd(const float* x, const float* w1, const float* b1, con
 int32_t amt_moe_combine_fwd(const float* y_rows, const int32_t* slot_pos, const int32_t* idx, const float* wts,
                             const float* shared, float shared_scale, float* out, int32_t n_tok, int32_t d, void* stream);
 
+/* ---- regression head VideoRegression(regModel='bimamba+') (model/video_regression.py:104-245) ---- */
+/* Depthwise causal Conv1d(kernel K, padding K-1)[..., :L] + SiLU of MambaBlock.forward (mamba.py:172-175,268-272):
+ * x (B,L,C) with row stride ldx, w (C,K) = conv1d.weight (C,1,K), y (B,L,C).  reverse = 1 evaluates the block of the
+ * time-flipped sequence and returns it un-flipped (the backward branch of bimamba.py:171-185 without the two flips). */
+int32_t amt_dwconv1d_silu_fwd(const float* x, int32_t ldx, const float* w, const float* bias, float* y,
+                              int32_t B, int32_t L, int32_t C, int32_t K, int32_t reverse, void* stream);
+/* MambaBlock.ssm + gate (mamba.py:291-354, 281-287): delta = softplus(delta_raw + dt_bias), A = -exp(A_log) (ED,N),
+ * h_t = exp(delta A) h_{t-1} + delta B_t x_t, y_t = h_t . C_t + D x_t, out = y*silu(z) [+ x*(1 - sigmoid(silu(z))) for
+ * version 1 = "Mamba+"].  x / delta_raw / z / y are (B*L, ED) with their own row strides, Bm / Cm (B*L, N) with stride
+ * ld_bc (slices of the x_proj output).  N = 16.  reverse as above. */
+int32_t amt_selective_scan_fwd(const float* x, int32_t ldx, const float* delta_raw, int32_t ld_delta, const float* dt_bias,
+                               const float* A_log, const float* Bm, const float* Cm, int32_t ld_bc, const float* D,
+                               const float* z, int32_t ldz, float* y, int32_t ldy, int32_t B, int32_t L, int32_t ED,
+                               int32_t N, int32_t version, int32_t reverse, void* stream);
+/* out[row] = [a[row][0:da] | b[row][0:db] | 0 ...] (ld_out columns): cat(semantic, emotion) of get_feature
+ * (video_regression.py:199-216), zero-padded to the GEMM's K step. */
+int32_t amt_concat2_fwd(const float* a, int32_t da, const float* b, int32_t db, float* out, int32_t rows, int32_t ld_out,
+                        void* stream);
+/* amt_linear_fwd with leading dimensions and an activation: y = act(x[M,K](ldx) . w[N,K](ldw)^T + bias (+ resid(ldr)));
+ * act 0 none, 1 ReLU, 2 sigmoid (the classifier head, video_regression.py:188-197).  K % 32 == 0. */
+int32_t amt_linear_ex_fwd(const float* x, int32_t ldx, const float* w, int32_t ldw, const float* bias, const float* resid,
+                          int32_t ldr, float* y, int32_t ldy, int32_t M, int32_t N, int32_t K, int32_t act, void* stream);
+/* y = LayerNorm(x (+ resid)) + post : the "norm2(x_b + x) then x_f + x_b" step of bimamba.py:183-188 in one pass. */
+int32_t amt_layernorm_post_fwd(const float* x, const float* resid, const float* w, const float* b, const float* post,
+                               float* y, int32_t rows, int32_t dim, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

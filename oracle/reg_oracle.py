@@ -1,0 +1,119 @@
+"""CPU oracle of the reference's `VideoRegression(regModel='bimamba+')` forward.
+
+TEST INFRASTRUCTURE: only tests/, bench tools' cpu legs and `oracle/make_goldens_reg.py` import this; the product path
+never does.  A restatement in plain torch-CPU fp32 of
+
+    model/video_regression.py:199-245   get_feature / forward: cat(semantic, emotion) -> in_proj -> encoder -> 2 heads
+    model/bimamba.py:9-31,102-196       BiMambaEncoder of post-norm BiMambaEncoderLayer_V1
+    model/mamba.py:160-323              MambaBlock (use_version=1, "Mamba+"): in_proj, causal depthwise conv + SiLU,
+                                        x_proj / dt_proj / softplus, selective scan, the Mamba+ forget gate, out_proj
+
+with the selective scan written as the plain recurrence (`selective_scan_seq`, :325-354); the reference runs the same
+recurrence through a Blelloch parallel scan (`pscan.py`), which differs by fp32 rounding only.  PINNED by
+tests/golden/g_reg.npz (outputs of the reference class itself, `oracle/make_goldens_reg.py`).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+LN_EPS = 1e-5
+
+
+def linear(x, w, b=None):
+    y = x @ w.t()
+    return y if b is None else y + b
+
+
+def layer_norm(x, w, b, eps=LN_EPS):
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * w + b
+
+
+def causal_dwconv_silu(x, w, b):
+    """x (B,L,C); w (C,1,K) depthwise; nn.Conv1d(padding=K-1)[..., :L] (mamba.py:172-175,268-272): output l sees
+    inputs l-K+1 .. l."""
+    B, L, C = x.shape
+    K = w.shape[-1]
+    xp = F.pad(x, (0, 0, K - 1, 0))
+    y = torch.zeros_like(x)
+    for j in range(K):
+        y = y + xp[:, j:j + L] * w[:, 0, j]
+    return F.silu(y + b)
+
+
+def selective_scan(x, delta, A, Bm, Cm, D):
+    """h_t = exp(delta_t A) h_{t-1} + delta_t B_t x_t ; y_t = h_t . C_t + D x_t   (mamba.py:325-354)."""
+    Bsz, L, ED = x.shape
+    h = torch.zeros(Bsz, ED, A.shape[1], dtype=x.dtype)
+    ys = []
+    for t in range(L):
+        dA = torch.exp(delta[:, t].unsqueeze(-1) * A)
+        h = dA * h + (delta[:, t].unsqueeze(-1) * Bm[:, t].unsqueeze(1)) * x[:, t].unsqueeze(-1)
+        ys.append((h * Cm[:, t].unsqueeze(1)).sum(-1))
+    return torch.stack(ys, 1) + D * x
+
+
+def mamba_block(x, sd, p, version=1, collect=None):
+    """MambaBlock.forward (mamba.py:257-289) + ssm (:291-323).  sd keys under prefix p."""
+    N = sd[p + "A_log"].shape[1]
+    R = sd[p + "dt_proj.weight"].shape[1]
+    xz = linear(x, sd[p + "in_proj.weight"], sd.get(p + "in_proj.bias"))
+    xi, z = xz.chunk(2, dim=-1)
+    xc = causal_dwconv_silu(xi, sd[p + "conv1d.weight"], sd[p + "conv1d.bias"])
+    dbc = linear(xc, sd[p + "x_proj.weight"])
+    dr, Bm, Cm = torch.split(dbc, [R, N, N], dim=-1)
+    delta = F.softplus(linear(dr, sd[p + "dt_proj.weight"]) + sd[p + "dt_proj.bias"])
+    A = -torch.exp(sd[p + "A_log"].float())
+    y = selective_scan(xc, delta, A, Bm, Cm, sd[p + "D"].float())
+    zs = F.silu(z)
+    out = y * zs + xc * (1 - torch.sigmoid(zs)) if version == 1 else y * zs      # :283-287 (sigmoid of the SiLU'd gate)
+    if collect is not None:
+        collect.update(xc=xc, delta=delta, y=y, gated=out)
+    return linear(out, sd[p + "out_proj.weight"], sd.get(p + "out_proj.bias"))
+
+
+def bimamba_layer(x, sd, p):
+    """BiMambaEncoderLayer_V1.forward, norm_first=False (bimamba.py:171-196); dropout is identity in eval."""
+    xf = mamba_block(x, sd, p + "mamba_forward.")
+    xf = layer_norm(xf + x, sd[p + "norm1.weight"], sd[p + "norm1.bias"])
+    xb = mamba_block(torch.flip(x, dims=[1]), sd, p + "mamba_backward.")
+    xb = layer_norm(torch.flip(xb, dims=[1]) + x, sd[p + "norm2.weight"], sd[p + "norm2.bias"])
+    s = xf + xb
+    f = linear(torch.relu(linear(s, sd[p + "ffn.0.weight"], sd[p + "ffn.0.bias"])), sd[p + "ffn.3.weight"], sd[p + "ffn.3.bias"])
+    return layer_norm(f + s, sd[p + "norm3.weight"], sd[p + "norm3.bias"])
+
+
+def n_layers_of(sd):
+    n = 0
+    while f"model.layers.{n}.norm1.weight" in sd:
+        n += 1
+    return n
+
+
+def forward(sd, sem, emotion, collect=None):
+    """VideoRegression.forward (video_regression.py:199-245): returns (loudness_notedensity (B,S,2), instrument (B,S,40)).
+    Scene offset and motion are accepted by the reference's signature but not used (:205-213 are commented out)."""
+    sd = {k: v.float() for k, v in sd.items()}
+    vf = torch.cat([sem.float(), emotion.float()], dim=-1)
+    x = linear(vf, sd["in_proj.0.weight"], sd["in_proj.0.bias"])
+    if collect is not None:
+        collect["in_proj"] = x
+    for l in range(n_layers_of(sd)):
+        x = bimamba_layer(x, sd, f"model.layers.{l}.")
+        if collect is not None:
+            collect[f"layer{l}"] = x
+    ln_nd = linear(x, sd["regressor.weight"], sd["regressor.bias"])
+    inst = torch.sigmoid(linear(x, sd["classifier.0.weight"], sd["classifier.0.bias"]))
+    return ln_nd, inst
+
+
+def postprocess(ln_nd):
+    """The integer note density and loudness level the callers derive (generate.py:401-409, video2music.py:855-865):
+    column 0 = note density -> round, clip [0,40]; column 1 = loudness -> int(x*100), clip [0,50]."""
+    y = ln_nd.reshape(-1, 2).numpy()
+    import numpy as np
+    nd = np.clip(np.round(y[:, 0:1]).astype(int), 0, 40)
+    lv = np.clip((y[:, 1:2] * 100).astype(int), 0, 50)
+    return nd, lv

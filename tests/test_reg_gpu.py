@@ -1,0 +1,96 @@
+"""Regression head `VideoRegression(regModel='bimamba+')` on the HIP path vs the reference's own
+outputs (tests/golden/g_reg.npz) and vs the CPU oracle at the deployed size."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import reg_oracle as R
+from video2music_amd import ops, synthetic
+from video2music_amd.model.video_regression import VideoRegression
+from tests.test_reg_oracle import CASES, reg_sd
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3          # north star tolerance for fp32 paths (observed ~1e-5)
+
+
+def build(cfg, seed):
+    m = VideoRegression(**cfg).eval()
+    shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=seed).items()}
+    m.load_state_dict(sd, strict=True)
+    return m.cuda(), sd
+
+
+def test_regression_head_vs_reference_golden(golden):
+    g = golden("g_reg.npz")
+    m, _ = build(dict(n_layers=2, d_model=32, d_hidden=64, total_vf_dim=30, regModel="bimamba+"), seed=5)
+    for B, S in CASES:
+        sem, emo = torch.from_numpy(g[f"sem_B{B}_S{S}"]).cuda(), torch.from_numpy(g[f"emo_B{B}_S{S}"]).cuda()
+        with torch.no_grad():
+            ln_nd, inst = m(sem, None, None, emo)
+            feat = m.get_feature(sem, None, None, emo)
+        assert ln_nd.shape == (B, S, 2) and inst.shape == (B, S, 40)
+        for got, name in ((feat, "feat"), (ln_nd, "lnnd"), (inst, "inst")):
+            err = (got.cpu() - torch.from_numpy(g[f"{name}_B{B}_S{S}"])).abs().max().item()
+            assert err < 5e-5, (name, B, S, err)
+
+
+def test_scan_and_conv_kernels_vs_oracle_both_directions():
+    """Operator-level: ragged sizes (channels not a multiple of 16, L not a multiple of the 32-step stage), both
+    directions, both gate versions."""
+    gen = torch.Generator().manual_seed(1)
+    for (B, L, ED, K, rk) in ((1, 5, 16, 4, 2), (2, 77, 40, 4, 3), (3, 300, 256, 4, 8), (1, 33, 24, 3, 2)):
+        N = 16
+        xz = torch.randn(B * L, 2 * ED, generator=gen)
+        w, bias = torch.randn(ED, K, generator=gen) * 0.5, torch.randn(ED, generator=gen) * 0.1
+        dbc = torch.randn(B * L, (rk + 2 * N + 3) // 4 * 4, generator=gen)
+        draw = torch.randn(B * L, ED, generator=gen)
+        dtb, A_log, D = torch.randn(ED, generator=gen), torch.randn(ED, N, generator=gen) * 0.5, torch.randn(ED, generator=gen)
+        for reverse in (False, True):
+            xi = xz[:, :ED].reshape(B, L, ED)
+            src = torch.flip(xi, dims=[1]) if reverse else xi
+            ref_c = R.causal_dwconv_silu(src, w.view(ED, 1, K), bias)
+            got_c = ops.dwconv1d_silu(xz.cuda(), ED, w.cuda(), bias.cuda(), B, L, reverse).cpu().view(B, L, ED)
+            rc = torch.flip(ref_c, dims=[1]) if reverse else ref_c
+            assert (got_c - rc).abs().max() < 1e-5
+            for version in (0, 1):
+                fl = (lambda t: torch.flip(t, dims=[1])) if reverse else (lambda t: t)
+                xc = fl(rc)
+                delta = torch.nn.functional.softplus(fl(draw.view(B, L, ED)) + dtb)
+                Bm, Cm = fl(dbc[:, rk:rk + N].reshape(B, L, N)), fl(dbc[:, rk + N:rk + 2 * N].reshape(B, L, N))
+                y = R.selective_scan(xc, delta, -torch.exp(A_log), Bm, Cm, D)
+                zs = torch.nn.functional.silu(fl(xz[:, ED:].reshape(B, L, ED)))
+                ref = fl(y * zs + xc * (1 - torch.sigmoid(zs)) if version == 1 else y * zs)
+                got = ops.selective_scan(rc.reshape(B * L, ED).contiguous().cuda(), draw.cuda(), dtb.cuda(), A_log.cuda(), dbc.cuda(), rk,
+                                         D.cuda(), xz.cuda(), B, L, version=version, reverse=reverse).cpu().view(B, L, ED)
+                scale = ref.abs().max().item() + 1.0
+                assert (got - ref).abs().max().item() / scale < 2e-5, (B, L, ED, reverse, version)
+
+
+def test_deployed_size_vs_oracle_and_postprocessing():
+    """video2music.py:651 configuration (6 layers, d_model 128, d_hidden 256, 768+6 features), 300 frames: the HIP
+    head against the CPU oracle, and the integer note-density / loudness levels the callers derive from it."""
+    cfg = dict(n_layers=6, d_model=128, d_hidden=256, total_vf_dim=774, regModel="bimamba+")
+    m, sd = build(cfg, seed=2)
+    f = synthetic.synthetic_features(2, seed=9)
+    sem, emo = torch.from_numpy(f["semantic"]), torch.from_numpy(f["emotion"])
+    with torch.no_grad():
+        ln_nd, inst = m(sem.cuda(), None, None, emo.cuda())
+    ref_ln, ref_inst = R.forward(sd, sem, emo)
+    assert (ln_nd.cpu() - ref_ln).abs().max() < TOL and (inst.cpu() - ref_inst).abs().max() < TOL
+    nd, lv = R.postprocess(ln_nd.cpu())
+    rnd, rlv = R.postprocess(ref_ln)
+    assert (nd != rnd).mean() < 0.01 and (lv != rlv).mean() < 0.01          # rounding boundaries only
+    # weights reloaded in place are picked up (padded copies are rebuilt)
+    with torch.no_grad():
+        m.in_proj[0].weight.mul_(0.5)
+        ln2, _ = m(sem.cuda(), None, None, emo.cuda())
+    assert (ln2 - ln_nd).abs().max() > 1e-4
+
+
+def test_rejects_unbuilt_variants():
+    with pytest.raises(NotImplementedError):
+        VideoRegression(total_vf_dim=774, regModel="bilstm")
+    with pytest.raises(ValueError):
+        m, _ = build(dict(n_layers=1, d_model=32, d_hidden=64, total_vf_dim=30, regModel="bimamba+"), seed=0)
+        m(torch.zeros(1, 4, 20).cuda(), None, None, torch.zeros(1, 4, 6).cuda())

@@ -61,6 +61,11 @@ SIGNATURES = {
     "amt_moe_route_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "amt_glu_expert_fwd": [_P] * 9 + [_I, _I, _I, _P],
     "amt_moe_combine_fwd": [_P, _P, _P, _P, _P, _F, _P, _I, _I, _P],
+    "amt_dwconv1d_silu_fwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "amt_selective_scan_fwd": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "amt_concat2_fwd": [_P, _I, _P, _I, _P, _I, _I, _P],
+    "amt_linear_ex_fwd": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
+    "amt_layernorm_post_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
 }
 _RESTYPES = {"amt_last_error": C.c_char_p, "amt_decode_step_bytes": C.c_int64, "amt_moe_scratch_floats": C.c_int64}
 _NO_STATUS = set(_RESTYPES) | {"amt_abi_version"}

@@ -30,6 +30,7 @@ __device__ __forceinline__ void store_out(const GemmParams& p, int row, int col,
     if (p.rowadd) v += p.rowadd[(size_t)(row % p.rowadd_period) * p.N + col];
     if (p.resid) v += p.resid[(size_t)row * p.ldr + col];
     if (p.relu) v = fmaxf(v, 0.f);
+    if (p.sigmoid) v = 1.0f / (1.0f + __expf(-v));
     if (p.head_split == 0) {
         p.C[(size_t)row * p.ldc + col] = v;
     } else {
@@ -183,6 +184,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
         }
         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (p.sigmoid) {
+            v.x = 1.0f / (1.0f + __expf(-v.x)); v.y = 1.0f / (1.0f + __expf(-v.y));
+            v.z = 1.0f / (1.0f + __expf(-v.z)); v.w = 1.0f / (1.0f + __expf(-v.w));
+        }
         if (p.head_split == 0) {
             st4(p.C + (size_t)row * p.ldc + col, v);
         } else {

@@ -13,6 +13,7 @@ struct GemmParams {
     const float* rowadd; int rowadd_period;   // [period][N] row-periodic addend (positional encoding), or null
     float scale; int scale_cols;    // columns [0,scale_cols) are multiplied by scale after the bias (q * hd^-0.5)
     int relu;
+    int sigmoid;                    // v = 1/(1+exp(-v)) last (classifier heads)
     // head-split store: row=b*seq+s, col=part*d+h*hd+c -> C[part*part_stride + ((b*heads+h)*seq_cap+s)*hd+c]
     int head_split, hs_seq, hs_seq_cap, hs_d, hs_hd, hs_heads;
     size_t hs_part_stride;
@@ -32,9 +33,10 @@ int32_t amt_launch_gemm(const GemmParams& p, hipStream_t stream);
 
 // ---------------- normalisation / elementwise (norm.hip) ----------------
 // y = LayerNorm(x (+ resid)) * w + b ; optional second LayerNorm (w2,b2) applied on top (decoder.norm)
+// `post` (optional, [rows][dim]) is added to the normalised rows: y = LN(x + resid) + post
 int32_t amt_launch_layernorm(const float* x, const float* resid, const float* w, const float* b,
                              const float* w2, const float* b2, float* y, int rows, int dim, float eps,
-                             hipStream_t stream);
+                             hipStream_t stream, const float* post = nullptr);
 int32_t amt_launch_rmsnorm(const float* x, const float* w, float* y, int rows, int dim, float eps, hipStream_t stream);
 // rotary embedding on interleaved pairs: x viewed as [n0][seq][n2][hd], cache [>=seq][cache_half][2];
 // reproduces the reference's view(-1, seq, 1, hd/2, 2)[:n0] reinterpretation of the cache
@@ -124,6 +126,26 @@ int32_t amt_launch_transpose(const float* in, float* out, int R, int C, hipStrea
 // g[n] = sum_k Ws[n][k] ; c[n] = W[n].beta + b[n] ; dv[n] = Ws[n].bo   (fp64 accumulation)
 int32_t amt_launch_fold_vectors(const float* W, const float* Ws, const float* beta, const float* b, const float* bo,
                                 float* g, float* c, float* dv, int N, int K, hipStream_t stream);
+
+// ---------------- Mamba pieces of the regression head (mamba.hip) ----------------
+// y[b][l][c] = silu(bias[c] + sum_j w[c][j] * x[b][l-(K-1)+j][c])   (causal depthwise conv; reverse: the same on the
+// time-reversed sequence, results at the original positions)
+int32_t amt_launch_dwconv_silu(const float* x, int ldx, const float* w, const float* bias, float* y, int B, int L, int C, int K,
+                               int reverse, hipStream_t stream);
+struct ScanParams {
+    const float* x; int ldx;            // [B*L][ED] conv output
+    const float* draw; int ldd;         // [B*L][ED] dt_proj(delta) without bias
+    const float* dt_bias;               // [ED]
+    const float* A_log;                 // [ED][N]
+    const float* Bm; const float* Cm; int ldbc;   // [B*L][N] each (slices of the x_proj output)
+    const float* D;                     // [ED]
+    const float* z; int ldz;            // [B*L][ED] gate branch (pre-SiLU)
+    float* y; int ldy;                  // [B*L][ED] gated output
+    int B, L, ED, N, version, reverse;
+};
+int32_t amt_launch_selective_scan(const ScanParams& p, hipStream_t stream);
+// out[row] = [a[row][0:da] | b[row][0:db] | 0-pad to ld_out]
+int32_t amt_launch_concat2(const float* a, int da, const float* b, int db, float* out, int rows, int ld_out, hipStream_t stream);
 
 // ---------------- sampling head (sample.hip) ----------------
 struct SampleParams {

@@ -15,7 +15,8 @@ template <bool RMS>
 __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, const float* __restrict__ resid,
                                                    const float* __restrict__ w, const float* __restrict__ b,
                                                    const float* __restrict__ w2, const float* __restrict__ b2,
-                                                   float* __restrict__ y, int rows, int dim, float eps) {
+                                                   float* __restrict__ y, int rows, int dim, float eps,
+                                                   const float* __restrict__ post) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -95,7 +96,10 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, 
 #pragma unroll
     for (int c = 0; c < MAX_CHUNKS; ++c) {
         int i = (c * 64 + lane) * 4;
-        if (i < dim) st4(y + (size_t)row * dim + i, v[c]);
+        if (i < dim) {
+            if (post) { const float4 a = ld4(post + (size_t)row * dim + i); v[c].x += a.x; v[c].y += a.y; v[c].z += a.z; v[c].w += a.w; }
+            st4(y + (size_t)row * dim + i, v[c]);
+        }
     }
 }
 
@@ -159,16 +163,16 @@ __global__ void chord_embed_kernel(const int64_t* __restrict__ root, const int64
 
 int32_t amt_launch_layernorm(const float* x, const float* resid, const float* w, const float* b,
                              const float* w2, const float* b2, float* y, int rows, int dim, float eps,
-                             hipStream_t stream) {
+                             hipStream_t stream, const float* post) {
     AMT_CHECK_ARG(rows > 0 && dim > 0 && dim % 4 == 0 && dim <= 64 * 4 * MAX_CHUNKS, "layernorm: bad shape rows=%d dim=%d", rows, dim);
-    hipLaunchKernelGGL(norm_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, resid, w, b, w2, b2, y, rows, dim, eps);
+    hipLaunchKernelGGL(norm_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, resid, w, b, w2, b2, y, rows, dim, eps, post);
     AMT_LAUNCH_CHECK();
     return 0;
 }
 
 int32_t amt_launch_rmsnorm(const float* x, const float* w, float* y, int rows, int dim, float eps, hipStream_t stream) {
     AMT_CHECK_ARG(rows > 0 && dim > 0 && dim % 4 == 0 && dim <= 64 * 4 * MAX_CHUNKS, "rmsnorm: bad shape rows=%d dim=%d", rows, dim);
-    hipLaunchKernelGGL(norm_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, nullptr, w, nullptr, nullptr, nullptr, y, rows, dim, eps);
+    hipLaunchKernelGGL(norm_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, nullptr, w, nullptr, nullptr, nullptr, y, rows, dim, eps, nullptr);
     AMT_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,146 @@
+"""`VideoRegression` (reference model/video_regression.py:104-245) for `regModel='bimamba+'`, the default regression
+head of both callers (utilities/argument_generate_funcs.py:87-91, video2music.py:651): per video frame it predicts
+(note density, loudness) and 40 instrument probabilities from cat(semantic, emotion) — SURVEY.md §8 row f2.
+
+The module keeps the reference's parameter names (so `load_state_dict(torch.load(path))` works) and composes the
+library's kernels; no torch arithmetic runs in `forward`:
+
+    cat + zero-pad            amt_concat2_fwd
+    every nn.Linear           amt_linear_ex_fwd (bias / residual / ReLU / sigmoid in the GEMM epilogue)
+    Conv1d + SiLU             amt_dwconv1d_silu_fwd
+    softplus, scan, gate      amt_selective_scan_fwd
+    LayerNorms                amt_layernorm_post_fwd (residual in, `x_f + x_b` out)
+
+The backward Mamba block runs with `reverse=1` instead of `torch.flip` before and after (bimamba.py:171-185).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+INSTRUMENT_SIZE = 40            # utilities/constants.py:84
+
+
+class _MambaBlockParams(nn.Module):
+    """Parameters of MambaBlock (mamba.py:160-231) with bias=True, conv_bias=True, no inner layernorms."""
+
+    def __init__(self, d_model, d_state=16, expand=2, d_conv=4):
+        super().__init__()
+        self.d_inner, self.d_state, self.d_conv = expand * d_model, d_state, d_conv
+        self.dt_rank = math.ceil(d_model / 16)
+        self.in_proj = nn.Linear(d_model, 2 * self.d_inner)
+        self.conv1d = nn.Conv1d(self.d_inner, self.d_inner, d_conv, groups=self.d_inner, padding=d_conv - 1)
+        self.x_proj = nn.Linear(self.d_inner, self.dt_rank + 2 * d_state, bias=False)
+        self.dt_proj = nn.Linear(self.dt_rank, self.d_inner)
+        self.A_log = nn.Parameter(torch.log(torch.arange(1, d_state + 1, dtype=torch.float32).repeat(self.d_inner, 1)))
+        self.D = nn.Parameter(torch.ones(self.d_inner))
+        self.out_proj = nn.Linear(self.d_inner, d_model)
+
+
+class _BiMambaLayerParams(nn.Module):
+    """BiMambaEncoderLayer_V1 (bimamba.py:102-133), plain FFN."""
+
+    def __init__(self, d_model, d_hidden):
+        super().__init__()
+        self.mamba_forward = _MambaBlockParams(d_model)
+        self.mamba_backward = _MambaBlockParams(d_model)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d_model), nn.LayerNorm(d_model), nn.LayerNorm(d_model)
+        self.ffn = nn.Sequential(nn.Linear(d_model, d_hidden), nn.ReLU(), nn.Dropout(0.0), nn.Linear(d_hidden, d_model))
+
+
+class _BiMambaEncoderParams(nn.Module):
+    def __init__(self, d_model, d_hidden, n_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([_BiMambaLayerParams(d_model, d_hidden) for _ in range(n_layers)])
+
+
+class VideoRegression(nn.Module):
+    def __init__(self, n_layers=2, d_model=64, d_hidden=1024, dropout=0.1, use_KAN=False, max_sequence_video=300,
+                 total_vf_dim=0, regModel="bilstm", scene_embed=False, chord_embed=False):
+        super().__init__()
+        if regModel != "bimamba+":
+            raise NotImplementedError("only regModel='bimamba+' (the callers' default) is built; the LSTM/GRU/Mamba/MoE variants "
+                                      "of video_regression.py:124-178 are not")
+        if use_KAN or scene_embed or chord_embed:
+            raise NotImplementedError("use_KAN / scene_embed / chord_embed are outside this path")
+        if d_model % 32 != 0 or d_hidden % 32 != 0:
+            raise ValueError("d_model and d_hidden must be multiples of 32 (GEMM K step)")
+        self.n_layers, self.d_model, self.d_hidden = n_layers, d_model, d_hidden
+        self.max_seq_video, self.total_vf_dim, self.regModel = max_sequence_video, total_vf_dim, regModel
+        self.model = _BiMambaEncoderParams(d_model, d_hidden, n_layers)
+        self.in_proj = nn.Sequential(nn.Linear(total_vf_dim, d_model), nn.Dropout(dropout))
+        self.regressor = nn.Linear(d_model, 2)
+        self.classifier = nn.Sequential(nn.Linear(d_model, INSTRUMENT_SIZE), nn.Sigmoid())
+        self._derived_sig = None
+
+    # zero-padded copies of the weights whose K (or row count) does not fit the GEMM's steps (rebuilt when they change)
+    def _derived(self):
+        blocks = [m for l in self.model.layers for m in (l.mamba_forward, l.mamba_backward)]
+        ws = [self.in_proj[0].weight] + [m.dt_proj.weight for m in blocks]
+        xs = [m.x_proj.weight for m in blocks]
+        sig = tuple((w.data_ptr(), w._version) for w in ws + xs)
+        if sig != self._derived_sig:
+            dev = ws[0].device
+            F = self.total_vf_dim
+            self._Fpad = (F + 31) // 32 * 32
+            self._Win = torch.zeros(self.d_model, self._Fpad, device=dev)
+            self._Win[:, :F] = ws[0].detach()
+            self._Wdt = []
+            for w in ws[1:]:                       # (d_inner, dt_rank) -> (d_inner, 32): the GEMM reads dt | B | C[:..] x zeros
+                t = torch.zeros(w.shape[0], 32, device=dev)
+                t[:, :w.shape[1]] = w.detach()
+                self._Wdt.append(t)
+            self._Wx = []
+            for w in xs:                           # (dt_rank + 2N, d_inner): rows padded to a multiple of 4 (row stride of dbc)
+                t = torch.zeros((w.shape[0] + 3) // 4 * 4, w.shape[1], device=dev)
+                t[:w.shape[0]] = w.detach()
+                self._Wx.append(t)
+            self._derived_sig = sig
+
+    def _mamba(self, x, m, wdt, wx, B, L, resid, reverse):
+        """MambaBlock.forward on rows x (B*L, d) + the layer's residual add (out_proj epilogue)."""
+        R, N = m.dt_rank, m.d_state
+        if R + 2 * N < 32:
+            raise ValueError("dt_rank + 2*d_state < 32 is not supported")
+        xz = ops.linear_ex(x, m.in_proj.weight.detach(), m.in_proj.bias.detach())
+        xc = ops.dwconv1d_silu(xz, m.d_inner, m.conv1d.weight.detach().reshape(m.d_inner, m.d_conv).contiguous(),
+                               m.conv1d.bias.detach(), B, L, reverse)
+        dbc = ops.linear_ex(xc, wx)
+        draw = ops.linear_ex(dbc, wdt, K=32)
+        g = ops.selective_scan(xc, draw, m.dt_proj.bias.detach(), m.A_log.detach(), dbc, R, m.D.detach(), xz, B, L,
+                               version=1, reverse=reverse)
+        return ops.linear_ex(g, m.out_proj.weight.detach(), m.out_proj.bias.detach(), resid=resid)
+
+    def get_feature(self, feature_semantic_list, feature_scene_offset, feature_motion, feature_emotion):
+        """video_regression.py:199-238: (B, S, d_model) encoder output.  Scene offset and motion are not used."""
+        self._derived()
+        dev = self.regressor.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("video2music_amd has no CPU path: move the module to the GPU")
+        sem = feature_semantic_list.to(device=dev, dtype=torch.float32).contiguous()
+        emo = feature_emotion.to(device=dev, dtype=torch.float32).contiguous()
+        B, S = sem.shape[0], sem.shape[1]
+        if sem.shape[2] + emo.shape[2] != self.total_vf_dim:
+            raise ValueError(f"semantic ({sem.shape[2]}) + emotion ({emo.shape[2]}) features != total_vf_dim ({self.total_vf_dim})")
+        vf = ops.concat2(sem.view(B * S, -1), emo.view(B * S, -1), self._Fpad)
+        x = ops.linear_ex(vf, self._Win, self.in_proj[0].bias.detach())
+        for i, lyr in enumerate(self.model.layers):
+            xf = ops.layernorm_post(self._mamba(x, lyr.mamba_forward, self._Wdt[2 * i], self._Wx[2 * i], B, S, x, False),
+                                    lyr.norm1.weight.detach(), lyr.norm1.bias.detach(), eps=lyr.norm1.eps)
+            s = ops.layernorm_post(self._mamba(x, lyr.mamba_backward, self._Wdt[2 * i + 1], self._Wx[2 * i + 1], B, S, x, True),
+                                   lyr.norm2.weight.detach(), lyr.norm2.bias.detach(), post=xf, eps=lyr.norm2.eps)      # x_f + x_b
+            h = ops.linear_ex(s, lyr.ffn[0].weight.detach(), lyr.ffn[0].bias.detach(), act=1)
+            f = ops.linear_ex(h, lyr.ffn[3].weight.detach(), lyr.ffn[3].bias.detach(), resid=s)
+            x = ops.layernorm_post(f, lyr.norm3.weight.detach(), lyr.norm3.bias.detach(), eps=lyr.norm3.eps)
+        return x.view(B, S, self.d_model)
+
+    def forward(self, feature_semantic_list, feature_scene_offset, feature_motion, feature_emotion):
+        """-> (loudness_notedensity (B,S,2), instrument (B,S,40)) like video_regression.py:240-245."""
+        out = self.get_feature(feature_semantic_list, feature_scene_offset, feature_motion, feature_emotion)
+        B, S, d = out.shape
+        rows = out.view(B * S, d)
+        ln_nd = ops.linear_ex(rows, self.regressor.weight.detach(), self.regressor.bias.detach())
+        inst = ops.linear_ex(rows, self.classifier[0].weight.detach(), self.classifier[0].bias.detach(), act=2)
+        return ln_nd.view(B, S, 2), inst.view(B, S, INSTRUMENT_SIZE)

@@ -72,3 +72,52 @@ def chord_embed(roots, attrs, key, PR, PA, wkey, bias, pe):
     out = torch.empty(B * L, d, device=PR.device, dtype=torch.float32)
     _lib.call("amt_chord_embed_fwd", p(roots), p(attrs), p(key), p(PR), p(PA), p(wkey), p(bias), p(pe), p(out), B, L, d, _st())
     return out
+
+
+def _off(t, col):
+    """Pointer to column `col` of row 0 of a contiguous 2-D fp32 tensor (a strided slice for the *_ex entry points)."""
+    assert t.is_contiguous() and t.dtype == torch.float32
+    return C.c_void_p(t.data_ptr() + 4 * int(col))
+
+
+def linear_ex(x, w, b=None, resid=None, act=0, x_col=0, K=None, out=None):
+    """y = act(x[:, x_col:x_col+K] w[N,K]^T + b (+ resid)); act 0 none / 1 ReLU / 2 sigmoid.  K % 32 == 0."""
+    M, ldx = x.shape
+    N, ldw = w.shape
+    K = ldw if K is None else K
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32) if out is None else out
+    _lib.call("amt_linear_ex_fwd", _off(x, x_col), ldx, p(w), ldw, p(b), p(resid), N, p(y), N, M, N, K, int(act), _st())
+    return y
+
+
+def layernorm_post(x, w, b, resid=None, post=None, eps=1e-5):
+    """LayerNorm(x (+ resid)) + post."""
+    rows, dim = x.shape
+    y = torch.empty_like(x)
+    _lib.call("amt_layernorm_post_fwd", p(x), p(resid), p(w), p(b), p(post), p(y), rows, dim, float(eps), _st())
+    return y
+
+
+def concat2(a, b, ld_out):
+    """[a | b | 0-pad] row-wise; a (rows, da), b (rows, db)."""
+    rows, da = a.shape
+    out = torch.empty(rows, ld_out, device=a.device, dtype=torch.float32)
+    _lib.call("amt_concat2_fwd", p(a), da, p(b), b.shape[1], p(out), rows, ld_out, _st())
+    return out
+
+
+def dwconv1d_silu(xz, C_, w, bias, B, L, reverse=False):
+    """Causal depthwise conv + SiLU over the first C_ columns of xz (B*L, ld); w (C_, K)."""
+    y = torch.empty(B * L, C_, device=xz.device, dtype=torch.float32)
+    _lib.call("amt_dwconv1d_silu_fwd", p(xz), xz.shape[1], p(w), p(bias), p(y), B, L, C_, w.shape[1], int(reverse), _st())
+    return y
+
+
+def selective_scan(xc, draw, dt_bias, A_log, dbc, R, D, xz, B, L, version=1, reverse=False):
+    """Selective scan + gate.  xc, draw (B*L, ED); dbc (B*L, R+2N) = x_proj output (B at column R, C at R+N);
+    xz (B*L, 2*ED) = in_proj output (gate branch z at column ED)."""
+    ED, N = A_log.shape
+    y = torch.empty(B * L, ED, device=xc.device, dtype=torch.float32)
+    _lib.call("amt_selective_scan_fwd", p(xc), ED, p(draw), ED, p(dt_bias), p(A_log), _off(dbc, R), _off(dbc, R + N), dbc.shape[1],
+              p(D), _off(xz, ED), xz.shape[1], p(y), ED, B, L, ED, N, int(version), int(reverse), _st())
+    return y

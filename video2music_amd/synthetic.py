@@ -31,6 +31,13 @@ def fill_tensor(name: str, shape, seed: int = 0) -> np.ndarray:
     leaf = name.split(".")[-1]
     if leaf == "Er":                                  # rpr.py:148 uses torch.rand -> [0,1)
         t = rs.uniform(0.0, 1.0, size=shape)
+    elif leaf == "A_log":                             # mamba.py:208-219: S4D-real init log(1..N), here with a little jitter
+        t = np.log(np.arange(1, shape[-1] + 1, dtype=np.float64))[None, :] + rs.uniform(-0.1, 0.1, size=shape)
+    elif name.endswith("dt_proj.bias"):               # mamba.py:198-204: softplus^-1 of dt log-uniform in [1e-3, 1e-1]
+        dt = np.exp(rs.uniform(np.log(1e-3), np.log(1e-1), size=shape))
+        t = dt + np.log(-np.expm1(-dt))
+    elif leaf == "D" and len(shape) == 1:             # mamba.py:221: ones
+        t = 1.0 + rs.uniform(-0.2, 0.2, size=shape)
     elif "norm" in name and leaf in ("weight", "scale"):
         t = 1.0 + rs.uniform(-0.2, 0.2, size=shape)
     elif "norm" in name and leaf == "bias":
