@@ -60,3 +60,32 @@ def test_v2_longer_sequence_vs_oracle(v2):
         y = m(root, root, attr, f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"])
     err = (y.cpu() - ref).abs().max().item()
     assert err < 1e-3, err
+
+
+def test_v2_cached_decode_equals_per_step_reforward(v2):
+    """generate over cached K/V (one token per step) gives the ids of the per-step re-forward of the decoder stack
+    (the reference's loop), for a 3-chord primer and 120 tokens through the GLU and the MoE layers, and the step
+    logits equal the last row of the teacher-forced forward."""
+    m, _ = v2
+    f = {k: v.cuda() for k, v in feats_t(synthetic.synthetic_features(1, seed=21)).items()}
+    kw = dict(feature_semantic_list=f["semantic"], feature_key=f["key"][0], feature_scene_offset=f["scene_offset"],
+              feature_motion=f["motion"], feature_emotion=f["emotion"], primer=torch.tensor([1, 66, 122]),
+              primer_root=torch.tensor([1, 6, 10]), primer_attr=torch.tensor([0, 0, 5]), target_seq_length=120, beam=0, sampler="argmax")
+    with torch.no_grad():
+        a = m.generate(use_cache=True, **kw)
+        b = m.generate(use_cache=False, **kw)
+    assert a.shape == (1, 120) and torch.equal(a, b)
+    # step logits vs the full forward over the generated prefix
+    from video2music_amd.utilities.constants import chord_to_root_attr
+    ids = a[0].cpu()
+    ra = [chord_to_root_attr(int(t)) for t in ids]
+    root = torch.tensor([[1, 6, 10] + [r for r, _ in ra[3:]]])
+    attr = torch.tensor([[0, 0, 5] + [x for _, x in ra[3:]]])
+    with torch.no_grad():
+        full = m(ids[None], root, attr, f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"])[0]
+        memory, B, S = m._encode_memory(f["semantic"], f["scene_offset"], f["motion"], f["emotion"])
+        st = m._cache_init(memory, S)
+        key = f["key"].reshape(-1)[:1].contiguous()
+        for t in range(119):
+            row = m._decode_step(root[:, t:t + 1].cuda(), attr[:, t:t + 1].cuda(), key, t, st)
+            assert (row - full[t]).abs().max().item() < 1e-5, t

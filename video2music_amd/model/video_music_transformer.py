@@ -413,8 +413,8 @@ class VideoMusicTransformer_V2(nn.Module):
     no additive positional encoding, RoPE (cache built for dim=d_model, applied through the raw (H, L, B, hd) view)
     inside every attention, three GLU feed-forward layers then three SharedMoELayer(6 experts, top-2) layers in both
     stacks, post-norm.  A composition of the library's operator kernels (``video2music_amd/ops.py``): ``generate`` runs the
-    video encoder once and re-runs the decoder stack every step (the reference re-runs both, :547-548); a KV-cached,
-    graph-captured decode is future work.
+    video encoder once and the decoder one token at a time over cached keys/values (the reference re-runs both stacks
+    on the whole prefix every step, :547-548).
     """
 
     def __init__(self, version_name="2.0", n_layers=6, num_heads=8, d_model=512, dim_feedforward=1024, dropout=0.1,
@@ -534,6 +534,53 @@ class VideoMusicTransformer_V2(nn.Module):
         t = t.view(L, B, d).permute(1, 0, 2).contiguous().view(B * L, d)
         return ops.linear(t, self.Wout.weight.detach(), self.Wout.bias.detach()).view(B, L, CHORD_SIZE)
 
+    # ---- KV-cached decode of one clip (B = 1) ----------------------------------------------------------------------
+    # For B = 1 the raw (H, L, B, hd) RoPE view is ordinary interleaved-pair RoPE over the full d_model vector at the
+    # true position, so row t of the decoder depends on tokens <= t only and the K/V rows of earlier
+    # positions never change: the decoder can run one token at a time over cached keys/values.  Every kernel computes
+    # its rows independently and in the same order as in the full forward, so the step's logits equal row t of `_decode`.
+    def _cache_init(self, memory, S):
+        from .. import ops
+        E, H = self.d_model, self.nhead
+        hd = E // H
+        dev = memory.device
+        st = {"cross": [], "self": [], "S": S}
+        for lyr in self.transformer.decoder.layers:
+            a = lyr.cross_attn
+            W, b = a.in_proj_weight.detach(), a.in_proj_bias.detach()
+            k = ops.linear(memory, W[E:2 * E], b[E:2 * E])
+            k = ops.rope(k.view(H, S, 1, hd), self._rope_cache).view(S, E)
+            v = ops.linear(memory, W[2 * E:], b[2 * E:])
+            st["cross"].append((k, v))
+            st["self"].append((torch.empty(self.max_seq_video, E, device=dev), torch.empty(self.max_seq_video, E, device=dev)))
+        return st
+
+    def _decode_step(self, root_t, attr_t, key, t, st):
+        """Logits (159,) for input position t given the cached positions < t (appends position t to the caches)."""
+        from .. import ops
+        E, H = self.d_model, self.nhead
+        hd = E // H
+        scale = 1.0 / math.sqrt(hd)
+        strides = (E, hd, E) * 4
+        x = ops.chord_embed(root_t, attr_t, key, self._PR, self._PA, self._wkey, self.Linear_chord.bias.detach(), self._zero_pe)
+        for lyr, (kc, vc), (kx, vx) in zip(self.transformer.decoder.layers, st["self"], st["cross"]):
+            a = lyr.self_attn
+            qkv = ops.linear(x, a.in_proj_weight.detach(), a.in_proj_bias.detach())                     # (1, 3E)
+            q = ops.rope(qkv[:, :E].view(1, 1, 1, E), self._rope_cache, pos=t).view(1, E)
+            ops.rope(qkv[:, E:2 * E].view(1, 1, 1, E), self._rope_cache, pos=t, out=kc[t:t + 1].view(1, 1, 1, E))
+            vc[t:t + 1].copy_(qkv[:, 2 * E:])
+            o = torch.empty(1, E, device=x.device, dtype=torch.float32)
+            ops.attention(q, kc, vc, strides, 1, H, 1, t + 1, hd, False, scale, o)
+            x = self._ln(ops.linear(o, a.out_proj.weight.detach(), a.out_proj.bias.detach(), resid=x), lyr.norm1)
+            a = lyr.cross_attn
+            W, b = a.in_proj_weight.detach(), a.in_proj_bias.detach()
+            q = ops.rope(ops.linear(x, W[:E], b[:E]).view(1, 1, 1, E), self._rope_cache, pos=t).view(1, E)
+            ops.attention(q, kx, vx, strides, 1, H, 1, st["S"], hd, False, scale, o)
+            x = self._ln(ops.linear(o, a.out_proj.weight.detach(), a.out_proj.bias.detach(), resid=x), lyr.norm2)
+            x = self._ln(self._ff(x, lyr.ff, 1, 1), lyr.norm3, resid=x)
+        x = self._ln(x, self.transformer.decoder.norm)
+        return ops.linear(x, self.Wout.weight.detach(), self.Wout.bias.detach())[0]
+
     def forward(self, x, x_root, x_attr, feature_semantic_list, feature_key, feature_scene_offset, feature_motion,
                 feature_emotion, mask=True):
         if mask is not True:
@@ -544,9 +591,11 @@ class VideoMusicTransformer_V2(nn.Module):
 
     def generate(self, feature_semantic_list=[], feature_key=None, feature_scene_offset=None, feature_motion=None,
                  feature_emotion=None, primer=None, primer_root=None, primer_attr=None, target_seq_length=300, beam=0,
-                 beam_chance=1.0, max_conseq_N=0, max_conseq_chord=2, temperature=1.0, sampler="categorical"):
-        """Reference loop (:518-609): one clip, full re-forward every step, decision on the host like the reference's
-        python loop (softmax[:157] / temperature, N and repeat suppression, Categorical sample or arg-max)."""
+                 beam_chance=1.0, max_conseq_N=0, max_conseq_chord=2, temperature=1.0, sampler="categorical", use_cache=True):
+        """Reference loop (:518-609) for one clip; the decision runs on the host like the reference's python loop
+        (softmax[:157] / temperature, N and repeat suppression, Categorical sample or arg-max).  The reference
+        re-runs the whole model every step; here the encoder runs once and the decoder one token at a time over
+        cached K/V (`use_cache=False` keeps the per-step re-forward of the decoder stack)."""
         from ..utilities.constants import chord_to_root_attr
         assert (not self.training), "Cannot generate while in training mode"
         if beam not in (0, 1):
@@ -564,9 +613,18 @@ class VideoMusicTransformer_V2(nn.Module):
         # recomputes the identical tensor inside each forward, :547-548)
         memory, B, S = self._encode_memory(feature_semantic_list, feature_scene_offset, feature_motion, feature_emotion)
         assert B == 1, "generate takes one clip, like the reference (:528-530)"
+        if T > self.max_seq_video:
+            raise ValueError(f"chord sequence longer than the RoPE cache ({self.max_seq_video}), like in the reference")
+        if use_cache:
+            dev_key = feature_key.to(device=dev, dtype=torch.float32).reshape(-1)[:1].contiguous()
+            st = self._cache_init(memory, S)
+            for t in range(P - 1):          # primer positions whose logits are not needed: fill the caches
+                self._decode_step(gen_root[:, t:t + 1].to(dev), gen_attr[:, t:t + 1].to(dev), dev_key, t, st)
         while cur < T:
-            logits = self._decode(gen_root[:, :cur], gen_attr[:, :cur], feature_key, memory, B, S)
-            row = logits[0, cur - 1].cpu()
+            if use_cache:
+                row = self._decode_step(gen_root[:, cur - 1:cur].to(dev), gen_attr[:, cur - 1:cur].to(dev), dev_key, cur - 1, st).cpu()
+            else:
+                row = self._decode(gen_root[:, :cur], gen_attr[:, :cur], feature_key, memory, B, S)[0, cur - 1].cpu()
             probs = torch.softmax(row / temperature, dim=-1)[:CHORD_END]
             if beam == 1:
                 gen[0, cur] = int(torch.topk(probs, 1)[1][0])

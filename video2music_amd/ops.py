@@ -33,11 +33,12 @@ def layernorm(x, w, b, resid=None, eps=1e-5):
     return y
 
 
-def rope(x, cache):
-    """x (n0, seq, n2, hd) contiguous, cache (>=seq, cache_half, 2): RotaryPositionalEmbeddings.forward."""
+def rope(x, cache, pos=0, out=None):
+    """x (n0, seq, n2, hd) contiguous, cache (>=pos+seq, cache_half, 2): RotaryPositionalEmbeddings.forward on the
+    cache rows pos..pos+seq-1 (pos > 0: one decode position); `out` receives the result (same numel)."""
     n0, seq, n2, hd = x.shape
-    y = torch.empty_like(x)
-    c = cache[:seq].contiguous()
+    y = torch.empty_like(x) if out is None else out
+    c = cache[pos:pos + seq].contiguous()
     _lib.call("amt_rope_fwd", p(x), p(c), p(y), n0, seq, n2, hd, cache.shape[1], _st())
     return y
 
