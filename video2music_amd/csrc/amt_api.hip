@@ -38,6 +38,7 @@ namespace {
 constexpr int V = 159;
 constexpr float LN_EPS = 1e-5f;
 constexpr int STEPS_PER_GRAPH = 8;
+constexpr int VS = 160;                  // V rounded up to the skinny GEMM's 16-column tiles
 
 struct Tensor {
     float* p = nullptr;
@@ -87,7 +88,11 @@ struct amt_handle {
     float *qb = nullptr, *ob = nullptr, *hb = nullptr, *keyb = nullptr;
     bool fold = false;                   // decode chain with folded LayerNorms (5 kernels per layer instead of 8)
     float *qraw = nullptr, *hraw = nullptr, *qkvraw = nullptr;          // raw projections of the un-normalised sums
-    float *tWs = nullptr, *tT = nullptr, *tWc = nullptr, *tComb = nullptr;   // load-time scratch of build_fold
+    float *tWs = nullptr, *tT = nullptr, *tWc = nullptr, *tComb = nullptr, *tWs2 = nullptr;   // load-time scratch of build_fold
+    // folded output head: packed [W''.W2 | W''] (W'' = Wout o g3 o gf), vectors h1|h2|dv|h3|h4|- (VS floats each), raw logits
+    float *pf_s = nullptr, *vs = nullptr, *lraw = nullptr;
+    // layer-0 q/k/v as table sums: rows of (root, attr, key column, position) projected through layer 0's in-proj
+    float *tab_r = nullptr, *tab_a = nullptr, *tab_k = nullptr, *tab_p = nullptr, *tab_cb = nullptr;
     int* pos = nullptr;
     unsigned* ticket = nullptr;
     int64_t *tokens = nullptr, *roots = nullptr, *attrs = nullptr;   // [maxB][Tcap]
@@ -205,6 +210,12 @@ SampleParams sample_params(amt_handle* h, float* logits_out, float* probs_out, i
     p.logits_out = logits_out; p.probs_out = probs_out;
     p.key = h->keyb; p.PR = h->PR; p.PA = h->PA; p.wkey = h->wkey; p.cbias = W(h, "Linear_chord.bias"); p.pe = h->pe;
     p.x_next = h->x_in; p.sample_external = external;
+    if (h->fold) {
+        p.lraw = h->lraw; p.ld_lraw = VS; p.h1 = h->vs; p.h2 = h->vs + VS; p.h3 = h->vs + 3 * VS; p.h4 = h->vs + 4 * VS;
+        p.tab_r = h->tab_r; p.tab_a = h->tab_a; p.tab_k = h->tab_k; p.tab_p = h->tab_p;
+        p.q0 = h->qb; p.kc0 = h->KVc; p.vc0 = h->KVc + h->kvc_part; p.H = h->H; p.hd = h->hd; p.cap = h->Tcap;
+        p.q_scale = 1.0f / sqrtf((float)h->hd);
+    }
     return p;
 }
 
@@ -231,7 +242,8 @@ struct StepProf {
 //   CA  cross-attention, norm1 finished in the prologue
 //   G2  [u2 | h_raw]   = [o | x1] . [Wo | Wc_b,W'_b]     out-proj + residual, and the raw FFN-up activations
 //   G3  [u3 | qkv_raw] = [relu(norm2-fix(h_raw)) | x2] . [W2 | Wc_c,W'_c]   FFN-down + residual, next layer's raw QKV
-// 5 dependent kernels per layer instead of 8 (layer 0 keeps its plain QKV projection in front).
+// 5 dependent kernels per layer instead of 8.  Layer 0's q/k/v are table sums written by the sampling head (its input is
+// a sum of embedding-table rows), the last G3 also emits the raw logits, so a step is 6*5 + 1 = 31 launches.
 int32_t enqueue_decoder_step_folded(amt_handle* h, hipStream_t s, StepProf* prof) {
     const int B = h->genB, d = h->d, dff = h->dff, H = h->H, hd = h->hd;
     const float qscale = 1.0f / sqrtf((float)hd);
@@ -246,14 +258,7 @@ int32_t enqueue_decoder_step_folded(amt_handle* h, hipStream_t s, StepProf* prof
         a.k = Kc; a.v = Vc; a.o = h->ob; a.B = B; a.H = H; a.hd = hd; a.cap = h->Tcap;
         a.pos = h->pos; a.Er = L.Er; a.er_len = h->Tcap;
         if (l == 0) {
-            DecodeGemmParams g{};
-            g.B = B; g.eps = LN_EPS; g.x = h->x_in; g.ldx = d; g.Wp = L.p_sa; g.bias = L.sa_b; g.N = 3 * d; g.K = d;
-            g.mode = 1; g.y = h->qb; g.ldy = d; g.scale = qscale; g.scale_cols = d;
-            g.kcache = Kc; g.vcache = Vc; g.H = H; g.hd = hd; g.cap = h->Tcap; g.pos = h->pos; g.d = d;
-            PROF_BEGIN();
-            if ((rc = amt_launch_decode_gemm(g, s))) return rc;
-            PROF_END(2);
-            a.q = h->qb;
+            a.q = h->qb;          // written, with this position's K/V rows, by the previous sampling head / embed_step (table sums)
         } else {
             const DecLayer& P = h->dec[l - 1];
             a.q = h->qkvraw; a.ldq = 3 * d; a.d = d; a.fold_u = h->u3; a.fold_g = P.vc; a.fold_c = P.vc + 3 * d;
@@ -294,6 +299,7 @@ int32_t enqueue_decoder_step_folded(amt_handle* h, hipStream_t s, StepProf* prof
         g3.K1 = dff; g3.K = dff + d; g3.fold_g = L.vb; g3.fold_c = L.vb + dff; g3.ln_w = L.n2w; g3.ln_b = L.n2b;
         g3.Wp = L.p_l2; g3.bias = L.l2b; g3.y = h->u3; g3.ldy = d; g3.n_split = d; g3.N = d;
         if (l + 1 < h->nl) { g3.N = 4 * d; g3.Wp2 = L.pf_c; g3.bias2 = L.vc + 6 * d; g3.y2 = h->qkvraw; g3.ldy2 = 3 * d; }
+        else { g3.N = d + VS; g3.Wp2 = h->pf_s; g3.bias2 = h->vs + 2 * VS; g3.y2 = h->lraw; g3.ldy2 = VS; }     // raw logits for the sampling head
         PROF_BEGIN();
         if ((rc = amt_launch_decode_gemm(g3, s))) return rc;
         PROF_END(2);
@@ -562,6 +568,14 @@ extern "C" int32_t amt_finalize(amt_handle* h) {
             if ((rc = dev_alloc(h, &h->tT, kmax * d))) return rc;
             if ((rc = dev_alloc(h, &h->tWc, nmax * kmax))) return rc;
             if ((rc = dev_alloc(h, &h->tComb, nmax * (kmax + d)))) return rc;
+            if ((rc = dev_alloc(h, &h->tWs2, (size_t)VS * d))) return rc;
+            if ((rc = dev_alloc(h, &h->vs, (size_t)6 * VS))) return rc;
+            if ((rc = dev_alloc(h, &h->lraw, (size_t)32 * VS))) return rc;
+            if ((rc = dev_alloc(h, &h->tab_r, (size_t)15 * 3 * d))) return rc;
+            if ((rc = dev_alloc(h, &h->tab_a, (size_t)16 * 3 * d))) return rc;
+            if ((rc = dev_alloc(h, &h->tab_k, (size_t)3 * d))) return rc;
+            if ((rc = dev_alloc(h, &h->tab_cb, (size_t)3 * d))) return rc;
+            if ((rc = dev_alloc(h, &h->tab_p, (size_t)h->Tcap * 3 * d))) return rc;
         }
         if ((rc = dev_alloc(h, &h->keyb, (size_t)32))) return rc;
         if ((rc = dev_alloc(h, &h->pos, (size_t)4))) return rc;
@@ -597,6 +611,32 @@ extern "C" int32_t amt_finalize(amt_handle* h) {
                 if ((rc = build_fold(h, Nx.sa_w, 3 * (int)d, D.n3w, D.n3b, Nx.sa_b, D.l2w, (int)dff, D.l2b, &D.pf_c, &D.vc, s))) return rc;
             }
         }
+    }
+    if (h->fold) {
+        // layer 0's in-projection of every table the decoder input is a sum of (video_music_transformer.py:984-1001,1029)
+        const DecLayer& D0 = h->dec[0];
+        const int d3 = 3 * (int)d;
+        if ((rc = amt_launch_gemm(gemm_params(h->PR, (int)d, D0.sa_w, (int)d, h->tab_r, d3, 15, d3, (int)d, nullptr), s))) return rc;
+        if ((rc = amt_launch_gemm(gemm_params(h->PA, (int)d, D0.sa_w, (int)d, h->tab_a, d3, 16, d3, (int)d, nullptr), s))) return rc;
+        if ((rc = amt_launch_gemm(gemm_params(h->wkey, (int)d, D0.sa_w, (int)d, h->tab_k, d3, 1, d3, (int)d, nullptr), s))) return rc;
+        if ((rc = amt_launch_gemm(gemm_params(bc, (int)d, D0.sa_w, (int)d, h->tab_cb, d3, 1, d3, (int)d, nullptr), s))) return rc;
+        GemmParams gp = gemm_params(h->pe, (int)d, D0.sa_w, (int)d, h->tab_p, d3, h->Tcap, d3, (int)d, D0.sa_b);
+        gp.rowadd = h->tab_cb; gp.rowadd_period = 1;
+        if ((rc = amt_launch_gemm(gp, s))) return rc;
+        // output head folded through norm3 of the last layer and decoder.norm (see SampleParams::lraw)
+        const DecLayer& DL = h->dec[h->nl - 1];
+        if ((rc = amt_launch_scale_cols(Wout, dnw, h->tWs2, V, (int)d, s))) return rc;                 // Wout o gf
+        if ((rc = amt_launch_scale_cols(h->tWs2, DL.n3w, h->tWs, V, (int)d, s))) return rc;            // W'' = Wout o gf o g3
+        if ((rc = amt_launch_transpose(DL.l2w, h->tT, (int)d, (int)dff, s))) return rc;
+        if ((rc = amt_launch_gemm(gemm_params(h->tWs, (int)d, h->tT, (int)d, h->tWc, (int)dff, V, (int)dff, (int)d, nullptr), s))) return rc;
+        const size_t ld = (size_t)(dff + d) * sizeof(float);
+        AMT_HIP(hipMemcpy2DAsync(h->tComb, ld, h->tWc, (size_t)dff * sizeof(float), (size_t)dff * sizeof(float), V, hipMemcpyDeviceToDevice, s));
+        AMT_HIP(hipMemcpy2DAsync(h->tComb + dff, ld, h->tWs, (size_t)d * sizeof(float), (size_t)d * sizeof(float), V, hipMemcpyDeviceToDevice, s));
+        if ((rc = pack(h, h->tComb, V, (int)(dff + d), &h->pf_s, s))) return rc;
+        AMT_HIP(hipMemsetAsync(h->vs, 0, (size_t)6 * VS * sizeof(float), s));
+        // h1 = rowsum(W''), h2 = (Wout o gf).b3, dv = W''.b2 ; h3 = rowsum(Wout o gf), h4 = Wout.bf + bout
+        if ((rc = amt_launch_fold_vectors(h->tWs2, h->tWs, DL.n3b, nullptr, DL.l2b, h->vs, h->vs + VS, h->vs + 2 * VS, V, (int)d, s))) return rc;
+        if ((rc = amt_launch_fold_vectors(Wout, h->tWs2, dnb, bout, DL.l2b, h->vs + 3 * VS, h->vs + 4 * VS, h->vs + 5 * VS, V, (int)d, s))) return rc;
     }
     AMT_HIP(hipDeviceSynchronize());
     // captured graphs hold pointers that stay valid (weights reload in place), nothing to invalidate

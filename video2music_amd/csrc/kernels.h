@@ -167,6 +167,15 @@ struct SampleParams {
     const float* key; const float* PR; const float* PA; const float* wkey; const float* cbias; const float* pe;
     float* x_next;                   // [B][d]
     int sample_external;             // 1: do not pick a token (host samples from probs_out), only write probs
+    // Folded output head (lraw != null): the last skinny GEMM already produced lraw = u . (Wout o g3 o gf)^T (ld_lraw
+    // floats per clip); with the statistics (mu, rstd) of u and (m2, rstd2) of LayerNorm3(u) the logits are
+    //   rstd2 * (rstd * (lraw - mu*h1) + h2 - m2*h3) + h4      (h1..h4: [159] vectors built at weight load)
+    const float* lraw; int ld_lraw; const float* h1; const float* h2; const float* h3; const float* h4;
+    // Layer-0 QKV of the next position as a table sum (tab_r != null): the decoder input is itself a sum of table
+    // rows (root, attr, key, position), so its projection is one too:  qkv = TR[root] + TA[attr] + key*tk + TP[pos]
+    // ([.][3d] tables).  q (x q_scale) goes to q0 [B][d], k / v into layer 0's cache row of that position.
+    const float* tab_r; const float* tab_a; const float* tab_k; const float* tab_p;
+    float* q0; float* kc0; float* vc0; int H, hd, cap; float q_scale;
 };
 int32_t amt_launch_sample(const SampleParams& p, hipStream_t stream);
 // writes x_next for position *pos from the token sequences (start of generate / external sampling)

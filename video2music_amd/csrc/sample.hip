@@ -33,6 +33,24 @@ __device__ __forceinline__ void write_next_input(const SampleParams& p, int b, i
         o.w = ((pr.w + pa.w) + kv * wk.w + bb.w) + pp.w;
         st4(p.x_next + (size_t)b * p.d + c, o);
     }
+    if (p.tab_r) {          // layer 0's q / k / v of position `cur` (same summation order as x above)
+        const int d = p.d, d3 = 3 * p.d;
+        for (int c = threadIdx.x * 4; c < d3; c += blockDim.x * 4) {
+            const float4 tr = ld4(p.tab_r + (size_t)root * d3 + c), ta = ld4(p.tab_a + (size_t)attr * d3 + c);
+            const float4 tk = ld4(p.tab_k + c), tp = ld4(p.tab_p + (size_t)cur * d3 + c);
+            float4 o;
+            o.x = ((tr.x + ta.x) + kv * tk.x) + tp.x; o.y = ((tr.y + ta.y) + kv * tk.y) + tp.y;
+            o.z = ((tr.z + ta.z) + kv * tk.z) + tp.z; o.w = ((tr.w + ta.w) + kv * tk.w) + tp.w;
+            if (c < d) {
+                o.x *= p.q_scale; o.y *= p.q_scale; o.z *= p.q_scale; o.w *= p.q_scale;
+                st4(p.q0 + (size_t)b * d + c, o);
+            } else {
+                const int nn = c < 2 * d ? c - d : c - 2 * d;
+                const int hh = nn / p.hd, cc = nn - hh * p.hd;
+                st4((c < 2 * d ? p.kc0 : p.vc0) + (((size_t)b * p.H + hh) * p.cap + cur) * p.hd + cc, o);
+            }
+        }
+    }
 }
 
 __device__ __forceinline__ void advance_pos(const SampleParams& p, int t) {
@@ -240,6 +258,146 @@ __global__ __launch_bounds__(NWS * 64) void sample_kernel(SampleParams p) {
     }
 }
 
+// Output head when the last skinny GEMM already produced the raw logits (SampleParams::lraw): wave 0 computes the two
+// LayerNorms' statistics of the clip's row, fixes the 159 raw logits, takes the decision; the whole block then writes
+// the next input.  Same decision code as sample_kernel.
+template <int KCH>
+__global__ __launch_bounds__(256) void sample_fold_kernel(SampleParams p) {
+    __shared__ int s_tok;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = p.d;
+    const int t = *p.pos, cur = t + 1;
+    if (wave == 0) {
+        const float inv_d = 1.0f / (float)d;
+        float4 v[KCH];
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            const int i = (c * 64 + lane) * 4;
+            v[c] = (i < d) ? ld4(p.u + (size_t)b * p.ldu + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float raw[3], a1[3], a2[3], a3[3], a4[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int n = lane + 64 * k, nc = min(n, V - 1);
+            raw[k] = p.lraw[(size_t)b * p.ld_lraw + nc];
+            a1[k] = p.h1[nc]; a2[k] = p.h2[nc]; a3[k] = p.h3[nc]; a4[k] = p.h4[nc];
+        }
+        float mu[2], rs[2];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) s += v[c].x + v[c].y + v[c].z + v[c].w;
+            const float mean = wave_sum(s) * inv_d;
+            float q = 0.f;
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) {
+                const int i = (c * 64 + lane) * 4;
+                if (i < d) {
+                    const float dx = v[c].x - mean, dy = v[c].y - mean, dz = v[c].z - mean, dw = v[c].w - mean;
+                    q += dx * dx + dy * dy + dz * dz + dw * dw;
+                }
+            }
+            const float rstd = rsqrtf(wave_sum(q) * inv_d + p.eps);
+            mu[pass] = mean; rs[pass] = rstd;
+            if (pass == 0) {
+#pragma unroll
+                for (int c = 0; c < KCH; ++c) {
+                    const int i = (c * 64 + lane) * 4;
+                    if (i < d) {
+                        const float4 g = ld4(p.ln_w + i), h = ld4(p.ln_b + i);
+                        v[c].x = (v[c].x - mean) * rstd * g.x + h.x; v[c].y = (v[c].y - mean) * rstd * g.y + h.y;
+                        v[c].z = (v[c].z - mean) * rstd * g.z + h.z; v[c].w = (v[c].w - mean) * rstd * g.w + h.w;
+                    }
+                }
+            }
+        }
+        float x[3], pr[3];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int n = lane + 64 * k;
+            x[k] = rs[1] * (rs[0] * (raw[k] - mu[0] * a1[k]) + a2[k] - mu[1] * a3[k]) + a4[k];
+            if (n >= V) x[k] = -INFINITY;
+            else if (p.logits_out) p.logits_out[((size_t)t * p.B + b) * V + n] = x[k];
+            mx = fmaxf(mx, x[k]);
+        }
+        mx = wave_max(mx);
+        float se = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            pr[k] = (lane + 64 * k < V) ? __expf(x[k] - mx) : 0.f;
+            se += pr[k];
+        }
+        se = wave_sum(se);
+        int prev = -1;
+        if (p.beam == 0) {
+            if (cur >= p.max_conseq_chord && cur >= 1) {
+                prev = (int)p.tokens[(size_t)b * p.T + cur - 1];
+                for (int k = 1; k < p.max_conseq_chord; ++k)
+                    if ((int)p.tokens[(size_t)b * p.T + cur - 1 - k] != prev) prev = -1;
+            }
+        }
+        float ps = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int n = lane + 64 * k;
+            pr[k] = (n < VP) ? pr[k] / se : 0.f;               // softmax(...)[:157]
+            if (p.beam == 0) {
+                if (n == 0 && p.max_conseq_N == 0) pr[k] = 0.f;
+                if (n == prev) pr[k] = 0.f;
+            }
+            ps += pr[k];
+        }
+        ps = wave_sum(ps);
+        if (p.probs_out) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (lane + 64 * k < VP) p.probs_out[(size_t)b * VP + lane + 64 * k] = pr[k];
+        }
+        float bv = -1.f;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int n = lane + 64 * k;
+            const float pn = (p.beam == 0) ? pr[k] / ps : pr[k];   // Categorical normalises its probs
+            if (n < VP && pn > bv) { bv = pn; bi = n; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) s_tok = bi;
+    }
+    __syncthreads();
+
+    if (!p.sample_external && cur < p.T) {
+        int tok, root, attr;
+        if (cur < p.n_primer) {
+            tok = (int)p.tokens[(size_t)b * p.T + cur];
+            root = (int)p.roots[(size_t)b * p.T + cur];
+            attr = (int)p.attrs[(size_t)b * p.T + cur];
+        } else {
+            tok = s_tok;
+            if (p.beam == 0) {
+                root = tok == 0 ? 0 : (tok - 1) / 13 + 1;
+                attr = tok == 0 ? 1 : (tok - 1) % 13 + 1;
+            } else {
+                root = ROOT_PAD; attr = ATTR_PAD;
+            }
+            if (tid == 0) {
+                p.tokens[(size_t)b * p.T + cur] = tok;
+                p.roots[(size_t)b * p.T + cur] = root;
+                p.attrs[(size_t)b * p.T + cur] = attr;
+            }
+        }
+        write_next_input(p, b, cur, root, attr);
+        advance_pos(p, t);
+    }
+}
+
 // x_next for position *pos from the stored sequences (first step of generate, or after the host
 // committed an externally sampled token at position *pos + advance)
 __global__ __launch_bounds__(256) void embed_step_kernel(SampleParams p, int advance) {
@@ -270,6 +428,17 @@ __global__ __launch_bounds__(256) void embed_step_kernel(SampleParams p, int adv
 
 int32_t amt_launch_sample(const SampleParams& p, hipStream_t stream) {
     AMT_CHECK_ARG(p.B > 0 && p.d % 4 == 0 && p.d <= 1024, "sample: bad shape B=%d d=%d", p.B, p.d);
+    if (p.lraw) {
+        AMT_CHECK_ARG(p.h1 && p.h2 && p.h3 && p.h4 && p.ln_w && p.ln_b && p.ld_lraw >= V, "sample: incomplete folded head");
+        switch ((p.d + 255) / 256) {
+            case 1: hipLaunchKernelGGL(sample_fold_kernel<1>, dim3(p.B), dim3(256), 0, stream, p); break;
+            case 2: hipLaunchKernelGGL(sample_fold_kernel<2>, dim3(p.B), dim3(256), 0, stream, p); break;
+            case 3: hipLaunchKernelGGL(sample_fold_kernel<3>, dim3(p.B), dim3(256), 0, stream, p); break;
+            default: hipLaunchKernelGGL(sample_fold_kernel<4>, dim3(p.B), dim3(256), 0, stream, p); break;
+        }
+        AMT_LAUNCH_CHECK();
+        return 0;
+    }
     switch ((p.d + 255) / 256) {
         case 1: hipLaunchKernelGGL(sample_kernel<1>, dim3(p.B), dim3(NWS * 64), 0, stream, p); break;
         case 2: hipLaunchKernelGGL(sample_kernel<2>, dim3(p.B), dim3(NWS * 64), 0, stream, p); break;
