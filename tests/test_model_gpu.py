@@ -132,6 +132,20 @@ def test_folded_and_plain_decode_chains_agree(monkeypatch):
     assert 0 < err < 1e-4, err        # > 0: the two chains really are different arithmetic
 
 
+def test_top1_branch_in_one_pass_equals_the_step_loop(model1):
+    """beam=1 (oracle G1) never feeds its ids back, so one teacher-forced forward over (primer, PAD, ...) gives the
+    same ids as T-1 decode steps; per-clip primers of length 3."""
+    m, _ = model1
+    f = cu(feats_t(synthetic.synthetic_features(4, seed=31)))
+    prim = torch.tensor([[[1, 1, 0], [66, 6, 0], [122, 10, 5]]] * 4)
+    prim[2, 1] = torch.tensor([5, 1, 4])
+    a = m.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], prim[:, :, 0], prim[:, :, 1], prim[:, :, 2],
+                         target_seq_length=80, beam=1)
+    b = m.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], prim[:, :, 0], prim[:, :, 1], prim[:, :, 2],
+                         target_seq_length=80, beam=1, one_pass_top1=False)
+    assert a.shape == (4, 80) and torch.equal(a, b) and torch.equal(a[:, :3].cpu(), prim[:, :, 0])
+
+
 def test_sampled_generate_is_valid_and_seeded(model1):
     m, _ = model1
     f = cu(feats_t(synthetic.synthetic_features(2, seed=5)))

@@ -315,12 +315,16 @@ class VideoMusicTransformer(nn.Module):
 
     def generate_batch(self, feature_semantic_list, feature_key, feature_scene_offset, feature_motion, feature_emotion,
                        primer, primer_root, primer_attr, target_seq_length=300, beam=0, beam_chance=1.0,
-                       max_conseq_N=0, max_conseq_chord=2, sampler="categorical", return_logits=False):
+                       max_conseq_N=0, max_conseq_chord=2, sampler="categorical", return_logits=False, one_pass_top1=True):
         """Batched generate: features (B,S,·), primer (P,) shared or (B,P) per clip -> LongTensor (B,T).
 
         beam=1 is the reference's deterministic top-1 branch (oracle G1; generated ids never feed
         back, :1078-1084).  beam=0 is the sampling branch (:1085-1128) with
         ``sampler="categorical"`` (random, torch RNG) or ``"argmax"`` (oracle G2).
+
+        In the beam=1 branch the model input of every generated position is the PAD root/attr pair, so all T-1 decisions
+        follow from ONE teacher-forced forward over (primer, PAD, PAD, ...): ``one_pass_top1`` (default) does exactly that
+        instead of T-1 decode steps (``one_pass_top1=False`` or ``return_logits=True`` keep the step loop).
         """
         assert (not self.training), "Cannot generate while in training mode"
         if beam not in (0, 1):
@@ -340,6 +344,19 @@ class VideoMusicTransformer(nn.Module):
         assert all(p.shape == prim[0].shape for p in prim), "primer / primer_root / primer_attr shapes differ"
         assert (not per_clip) or prim[0].shape[0] == B
         tokens = torch.empty(B, T, device=dev, dtype=torch.long)
+        if beam == 1 and one_pass_top1 and not return_logits and T > P:
+            roots = torch.full((B, T - 1), CHORD_ROOT_PAD, device=dev, dtype=torch.long)
+            attrs = torch.full((B, T - 1), CHORD_ATTR_PAD, device=dev, dtype=torch.long)
+            roots[:, :P], attrs[:, :P] = prim[1], prim[2]
+            lg = torch.empty(B, T - 1, CHORD_SIZE, device=dev, dtype=torch.float32)
+            for b0 in range(0, B, MAX_DECODE_BATCH):
+                sl = slice(b0, min(B, b0 + MAX_DECODE_BATCH))
+                self._encode(h, sem, scene, motion, emotion, sl)
+                _lib.call("amt_prefill", h, sl.stop - sl.start, T - 1, _lib.ptr(roots[sl].contiguous()), _lib.ptr(attrs[sl].contiguous()),
+                          _lib.ptr(key[sl].contiguous()), _lib.ptr(lg[sl]), None, -1, _lib.stream_ptr())
+            tokens[:, :P] = prim[0]
+            tokens[:, P:] = lg[:, P - 1:, :CHORD_END].argmax(dim=-1)          # top-1 of softmax(...)[:157] (:1070-1084)
+            return tokens
         logits = torch.zeros(T, B, CHORD_SIZE, device=dev) if return_logits else None
         for b0 in range(0, B, MAX_DECODE_BATCH):
             sl = slice(b0, min(B, b0 + MAX_DECODE_BATCH))
