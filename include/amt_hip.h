@@ -189,6 +189,24 @@ int32_t amt_glu_expert_fwd(const float* x, const float* w1, const float* b1, con
 int32_t amt_moe_combine_fwd(const float* y_rows, const int32_t* slot_pos, const int32_t* idx, const float* wts,
                             const float* shared, float shared_scale, float* out, int32_t n_tok, int32_t d, void* stream);
 
+/* ---- VideoMusicTransformer_V2 '2.2': one KV-cached decode step of one clip ------------------------
+ * Issues, from one call, the launch sequence of the decoder restricted to position t (reference
+ * video_music_transformer.py:437-516, custom_transformer.py:1250-1292): embedding of (root, attr, key), per layer RoPE
+ * self-attention over the cache (appends row t), RoPE cross-attention over the clip's video keys, GLU expert or
+ * SharedMoE(top-2), post-norm LayerNorms; decoder.norm; Wout -> logits_out[159].
+ * Every projection handles one row, so it runs on the skinny decode GEMM over weights packed once by
+ * amt_pack_weight_fwd (out: ceil(N/16)*16*K floats; the experts of a MoE layer are packed one after the other).
+ * tab: device pointers, 10 global (PR, PA, wkey, Linear_chord.bias, rope cache (max_seq, E/2, 2), decoder.norm w, b,
+ * packed Wout, Wout b, an int32 pair {0, 1}) then 32 per layer (packed self in_proj, its bias, packed out_proj, b,
+ * norm1 w, b, packed cross in_proj rows 0:E, its bias, packed out_proj, b, norm2 w, b, norm3 w, b, self K cache, V cache
+ * (max_seq, E), cross K (roped), V (S, E), router w (null = plain GLU layer), router b, packed linear1, b, packed gate, b,
+ * packed linear2, b (per expert, stacked, for a MoE layer), shared expert's six tensors (packed weights) or null).
+ * ws: amt_v2_step_ws_floats(E, dff, n_exp) floats.  E, dff multiples of 64, at most 1536. */
+int32_t amt_pack_weight_fwd(const float* w, float* out, int32_t N, int32_t K, void* stream);
+int64_t amt_v2_step_ws_floats(int32_t E, int32_t dff, int32_t n_exp);
+int32_t amt_v2_step(const void* const* tab, int32_t n_layers, int32_t H, int32_t E, int32_t dff, int32_t n_exp,
+                    int32_t S, int32_t t, int32_t root, int32_t attr, float key, float* logits_out, float* ws, void* stream);
+
 /* ---- regression head VideoRegression(regModel='bimamba+') (model/video_regression.py:104-245) ---- */
 /* Depthwise causal Conv1d(kernel K, padding K-1)[..., :L] + SiLU of MambaBlock.forward (mamba.py:172-175,268-272):
  * x (B,L,C) with row stride ldx, w (C,K) = conv1d.weight (C,1,K), y (B,L,C).  reverse = 1 evaluates the block of the

@@ -794,8 +794,10 @@ extern "C" int32_t amt_generate_run(amt_handle* h, int32_t n_steps, float* logit
     if (n_steps < 0 || n_steps > remaining) n_steps = remaining;
     int32_t rc;
     int left = n_steps;
+    static int spg = 0;
+    if (!spg) { const char* e = getenv("AMT_STEPS_PER_GRAPH"); spg = e && atoi(e) > 0 ? atoi(e) : STEPS_PER_GRAPH; }
     while (left > 0) {
-        const int ns = left >= STEPS_PER_GRAPH ? STEPS_PER_GRAPH : 1;
+        const int ns = left >= spg ? spg : 1;
         hipGraphExec_t exec;
         if ((rc = get_graph(h, ns, logits_out, &exec))) return rc;
         AMT_HIP(hipGraphLaunch(exec, s));

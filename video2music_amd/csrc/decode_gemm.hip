@@ -103,7 +103,8 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
     }
     // ---- 3. this wave's weight tiles (tile index clamped: surplus loads repeat the last tile) ----
     float4 wt[KCH];
-    const float* wbase = high ? p.Wp2 + (size_t)(nt - nts) * kt_n * 256 : p.Wp + (size_t)nt * kt_n * 256;
+    const int grp = p.sel ? *p.sel : 0;             // device-chosen weight group (mixture-of-experts, one token)
+    const float* wbase = high ? p.Wp2 + (size_t)(nt - nts) * kt_n * 256 : p.Wp + (size_t)grp * p.sel_w_stride + (size_t)nt * kt_n * 256;
 #pragma unroll
     for (int i = 0; i < KCH; ++i) wt[i] = ld4(wbase + ((size_t)min(kt0 + i, kt_n - 1) * 64 + lane) * 4);
     __builtin_amdgcn_sched_barrier(0);              // the scheduler must not sink any of these loads below this point
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
     // ---- 4. epilogue operands: issued behind the prologue so that no register of the prologue's arithmetic sits
     // next to a pending load (packed VALU ops read register pairs).  Absent operands read a zero word instead of
     // being masked after the load: a select on a loaded value would be scheduled early and wait for the weights ----
-    const float* bp = high ? p.bias2 : p.bias;
+    const float* bp = high ? p.bias2 : (p.bias ? p.bias + (size_t)grp * p.sel_b_stride : nullptr);
     const bool has_b = live && bp != nullptr, has_r = PRO != 2 && live && !high && p.mode == 0 && p.resid != nullptr;
     const float e_bias = *(has_b ? bp + (high ? n - p.n_split : n) : p.zero);
     float e_res = 0.f;
@@ -294,6 +295,7 @@ int32_t amt_launch_decode_gemm(const DecodeGemmParams& p_in, hipStream_t stream)
     else AMT_CHECK_ARG(p.ldx >= p.K, "decode_gemm: ldx=%d < K=%d", p.ldx, p.K);
     if (p.n_split) AMT_CHECK_ARG(p.x2 && p.n_split % 16 == 0 && p.n_split <= p.N && p.mode == 0 && (p.n_split == p.N || (p.Wp2 && p.y2)),
                                  "decode_gemm: bad column split %d of N=%d", p.n_split, p.N);
+    AMT_CHECK_ARG(!p.sel || p.n_split == 0, "decode_gemm: a device-selected weight group cannot be combined with a column split");
     if (p.pro == 1) AMT_CHECK_ARG(p.x2 && p.fold_g && p.fold_c && p.ln_w && p.ln_b && !p.resid, "decode_gemm: incomplete folded-FFN prologue");
     else AMT_CHECK_ARG(!p.ln_w || (!p.x2 && p.K <= 1024), "decode_gemm: the LayerNorm prologue takes a single source of K <= 1024");
     size_t lds = (size_t)MT * (p.K + XPAD) * sizeof(float);

@@ -114,6 +114,9 @@ struct DecodeGemmParams {
     // (bias, residual, ReLU as in mode 0) and go to y; columns [n_split,N) use Wp2 over all K columns, get
     // bias2[n - n_split] only and go to y2[row*ldy2 + n - n_split].  n_split == 0: no split.
     const float* Wp2; const float* bias2; float* y2; int ldy2, n_split;
+    // weight group chosen on the device (one token of a mixture-of-experts layer): Wp / Wp2-less launches only;
+    // the packed weight of group *sel starts sel_w_stride floats further, its bias sel_b_stride floats further
+    const int* sel; size_t sel_w_stride; int sel_b_stride;
     const float* zero;          // set by the launcher: zero words in global memory
 };
 int32_t amt_launch_decode_gemm(const DecodeGemmParams& p, hipStream_t stream);

@@ -1,0 +1,155 @@
+// One KV-cached decode step of VideoMusicTransformer_V2 '2.2' for one clip, issued from a single C call.
+//
+// The step is the launch sequence of `VideoMusicTransformer_V2._decode_step` (video2music_amd/model/
+// video_music_transformer.py; reference model/video_music_transformer.py:437-516 + custom_transformer.py:1250-1292
+// restricted to the newest position): chord embedding, then per decoder layer
+//   in-proj (q|k|v) -> RoPE(q), RoPE(k) into the cache row, v into the cache row -> attention over keys 0..t
+//   -> out-proj + residual -> LayerNorm -> cross q-proj -> RoPE -> attention over the clip's video keys
+//   -> out-proj + residual -> LayerNorm -> GLU expert or SharedMoE(6, top-2) -> residual LayerNorm,
+// then decoder.norm and Wout.  One row per projection: the dense 128x128-tile GEMM of the prefill path takes ~65 us for such
+// a launch (every K step exposes a full memory latency), so the projections run on the skinny decode GEMM over weights the
+// host packed once (amt_pack_weight_fwd); the two experts a token is routed to are picked on the device (weight group index
+// read by the kernel), so no routing result ever travels to the host.
+#include "../../include/amt_hip.h"
+#include "amt_common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int G_PTRS = 10, L_PTRS = 32;
+enum { G_PR, G_PA, G_WKEY, G_CBIAS, G_ROPE, G_FNW, G_FNB, G_WOUT, G_BOUT, G_SLOT01 };
+enum { L_SAW, L_SAB, L_SAOW, L_SAOB, L_N1W, L_N1B, L_CAW, L_CAB, L_CAOW, L_CAOB, L_N2W, L_N2B, L_N3W, L_N3B,
+       L_KC, L_VC, L_KX, L_VX, L_GATEW, L_GATEB, L_W1, L_B1, L_WG, L_BG, L_W2, L_B2, L_SW1, L_SB1, L_SWG, L_SBG, L_SW2, L_SB2 };
+
+__global__ void embed_one_kernel(int root, int attr, float kv, const float* __restrict__ PR, const float* __restrict__ PA,
+                                 const float* __restrict__ wkey, const float* __restrict__ bias, float* __restrict__ out, int d) {
+    for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
+        const float4 pr = ld4(PR + (size_t)root * d + c), pa = ld4(PA + (size_t)attr * d + c);
+        const float4 wk = ld4(wkey + c), bb = ld4(bias + c);
+        float4 o;        // the summation order of chord_embed_kernel with a zero positional row
+        o.x = ((pr.x + pa.x) + kv * wk.x + bb.x) + 0.f; o.y = ((pr.y + pa.y) + kv * wk.y + bb.y) + 0.f;
+        o.z = ((pr.z + pa.z) + kv * wk.z + bb.z) + 0.f; o.w = ((pr.w + pa.w) + kv * wk.w + bb.w) + 0.f;
+        st4(out + c, o);
+    }
+}
+
+__global__ void copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int n) {
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i < n) st4(dst + i, ld4(src + i));
+}
+
+// h = u * silu(g)   (GLUExpert.forward, moe.py:44-49)
+__global__ void glu_mul_kernel(const float* __restrict__ u, const float* __restrict__ g, float* __restrict__ h, int n) {
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i < n) {
+        const float4 a = ld4(u + i), b = ld4(g + i);
+        float4 o;
+        o.x = a.x * (b.x / (1.0f + __expf(-b.x))); o.y = a.y * (b.y / (1.0f + __expf(-b.y)));
+        o.z = a.z * (b.z / (1.0f + __expf(-b.z))); o.w = a.w * (b.w / (1.0f + __expf(-b.w)));
+        st4(h + i, o);
+    }
+}
+
+int32_t attn_one(const float* q, const float* k, const float* v, float* o, int E, int H, int hd, int Lk, hipStream_t s) {
+    AttnParams a{};
+    a.q = q; a.k = k; a.v = v; a.o = o;
+    a.q_bs = a.k_bs = a.v_bs = a.o_bs = (size_t)E;
+    a.q_hs = a.k_hs = a.v_hs = a.o_hs = (size_t)hd;
+    a.q_ls = a.k_ls = a.v_ls = a.o_ls = (size_t)E;
+    a.B = 1; a.H = H; a.Lq = 1; a.Lk = Lk; a.hd = hd; a.causal = 0; a.kv_group = 1; a.q_scale = 1.0f / sqrtf((float)hd);
+    return amt_launch_attn_prefill(a, s);
+}
+
+// one row through a pre-packed weight on the skinny GEMM: y[N] = x[K] . W^T + b (+ resid); optional device-chosen group
+int32_t lin(const float* x, const float* wp, const float* b, const float* resid, float* y, int N, int K, hipStream_t s,
+            const int* sel = nullptr, size_t sel_w = 0, int sel_b = 0) {
+    DecodeGemmParams g{};
+    g.B = 1; g.eps = 1e-5f; g.scale = 1.f; g.x = x; g.ldx = K; g.Wp = wp; g.bias = b; g.N = N; g.K = K;
+    g.resid = resid; g.ldr = N; g.y = y; g.ldy = N; g.sel = sel; g.sel_w_stride = sel_w; g.sel_b_stride = sel_b;
+    return amt_launch_decode_gemm(g, s);
+}
+
+// GLUExpert on one row: y = W2 ((W1 x + b1) * silu(Wg x + bg)) + b2 ; scratch 3*dff floats
+int32_t glu_one(const float* x, const float* w1, const float* b1, const float* wg, const float* bg, const float* w2, const float* b2,
+                float* y, float* scratch, int E, int dff, hipStream_t s, const int* sel = nullptr) {
+    float* g = scratch; float* u = g + dff; float* hh = u + dff;
+    const size_t sw = (size_t)dff * E;
+    int32_t rc;
+    if ((rc = lin(x, wg, bg, nullptr, g, dff, E, s, sel, sw, dff))) return rc;
+    if ((rc = lin(x, w1, b1, nullptr, u, dff, E, s, sel, sw, dff))) return rc;
+    hipLaunchKernelGGL(glu_mul_kernel, dim3(cdiv(dff, 1024)), dim3(256), 0, s, u, g, hh, dff);
+    AMT_LAUNCH_CHECK();
+    return lin(hh, w2, b2, nullptr, y, E, dff, s, sel, sw, E);
+}
+
+}  // namespace
+
+extern "C" int64_t amt_v2_step_ws_floats(int32_t E, int32_t dff, int32_t n_exp) {
+    (void)n_exp;
+    return (int64_t)16 * E + 4 * dff + 64;
+}
+
+extern "C" int32_t amt_pack_weight_fwd(const float* w, float* out, int32_t N, int32_t K, void* stream) {
+    AMT_CHECK_ARG(w && out && N > 0, "amt_pack_weight_fwd: bad argument");
+    return amt_launch_pack_weight(w, out, N, K, (hipStream_t)stream);
+}
+
+extern "C" int32_t amt_v2_step(const void* const* tab, int32_t n_layers, int32_t H, int32_t E, int32_t dff, int32_t n_exp,
+                               int32_t S, int32_t t, int32_t root, int32_t attr, float key, float* logits_out, float* ws,
+                               void* stream) {
+    AMT_CHECK_ARG(tab && logits_out && ws, "amt_v2_step: null pointer");
+    AMT_CHECK_ARG(n_layers > 0 && H > 0 && E % H == 0 && E % 64 == 0 && dff % 64 == 0 && E <= 1536 && dff <= 1536 && t >= 0 && S > 0,
+                  "amt_v2_step: bad shape (E and dff must be multiples of 64, at most 1536)");
+    hipStream_t s = (hipStream_t)stream;
+    const int hd = E / H;
+    auto G = [&](int i) { return (const float*)tab[i]; };
+    float* x = ws; float* y = x + E; float* qkv = y + E; float* q = qkv + 3 * E; float* o = q + E; float* u = o + E;
+    float* Y2 = u + E;                                    // two expert outputs [2][E]
+    float* ysh = Y2 + 2 * E;                              // shared expert output [E]
+    float* ffs = ysh + E;                                 // 3*dff GLU scratch
+    float* moe_w = ffs + 3 * dff;                         // routing weights [2], then indices [2]
+    int32_t* moe_idx = (int32_t*)(moe_w + 4);
+    int32_t rc;
+    hipLaunchKernelGGL(embed_one_kernel, dim3(1), dim3(128), 0, s, root, attr, key, G(G_PR), G(G_PA), G(G_WKEY), G(G_CBIAS), x, E);
+    AMT_LAUNCH_CHECK();
+    const float* rope_row = G(G_ROPE) + (size_t)t * E;    // cache row t: E/2 (cos, sin) pairs
+    for (int l = 0; l < n_layers; ++l) {
+        const void* const* L = tab + G_PTRS + (size_t)l * L_PTRS;
+        auto P = [&](int i) { return (const float*)L[i]; };
+        float* kc = (float*)L[L_KC]; float* vc = (float*)L[L_VC];
+        // self-attention
+        if ((rc = lin(x, P(L_SAW), P(L_SAB), nullptr, qkv, 3 * E, E, s))) return rc;
+        if ((rc = amt_launch_rope(qkv, rope_row, q, 1, 1, 1, E, E / 2, s))) return rc;
+        if ((rc = amt_launch_rope(qkv + E, rope_row, kc + (size_t)t * E, 1, 1, 1, E, E / 2, s))) return rc;
+        hipLaunchKernelGGL(copy_kernel, dim3(cdiv(E, 1024)), dim3(256), 0, s, qkv + 2 * E, vc + (size_t)t * E, E);
+        AMT_LAUNCH_CHECK();
+        if ((rc = attn_one(q, kc, vc, o, E, H, hd, t + 1, s))) return rc;
+        if ((rc = lin(o, P(L_SAOW), P(L_SAOB), x, u, E, E, s))) return rc;
+        if ((rc = amt_launch_layernorm(u, nullptr, P(L_N1W), P(L_N1B), nullptr, nullptr, x, 1, E, 1e-5f, s))) return rc;
+        // cross-attention over the clip's (roped) video keys
+        if ((rc = lin(x, P(L_CAW), P(L_CAB), nullptr, qkv, E, E, s))) return rc;
+        if ((rc = amt_launch_rope(qkv, rope_row, q, 1, 1, 1, E, E / 2, s))) return rc;
+        if ((rc = attn_one(q, P(L_KX), P(L_VX), o, E, H, hd, S, s))) return rc;
+        if ((rc = lin(o, P(L_CAOW), P(L_CAOB), x, u, E, E, s))) return rc;
+        if ((rc = amt_launch_layernorm(u, nullptr, P(L_N2W), P(L_N2B), nullptr, nullptr, x, 1, E, 1e-5f, s))) return rc;
+        // feed-forward: GLU expert (shallow layers) or shared mixture of experts (router, the two chosen experts read
+        // their weights through the device-side index, shared expert, weighted sum in expert-index order)
+        if (!L[L_GATEW]) {
+            if ((rc = glu_one(x, P(L_W1), P(L_B1), P(L_WG), P(L_BG), P(L_W2), P(L_B2), y, ffs, E, dff, s))) return rc;
+        } else {
+            if ((rc = amt_moe_route_fwd(x, P(L_GATEW), P(L_GATEB), moe_idx, moe_w, 1, E, n_exp, s))) return rc;
+            for (int slot = 0; slot < 2; ++slot)
+                if ((rc = glu_one(x, P(L_W1), P(L_B1), P(L_WG), P(L_BG), P(L_W2), P(L_B2), Y2 + (size_t)slot * E, ffs, E, dff, s, moe_idx + slot))) return rc;
+            const float* shared = nullptr;
+            if (L[L_SW1]) {
+                if ((rc = glu_one(x, P(L_SW1), P(L_SB1), P(L_SWG), P(L_SBG), P(L_SW2), P(L_SB2), ysh, ffs, E, dff, s))) return rc;
+                shared = ysh;
+            }
+            if ((rc = amt_moe_combine_fwd(Y2, (const int32_t*)tab[G_SLOT01], moe_idx, moe_w, shared, 0.5f, y, 1, E, s))) return rc;
+        }
+        if ((rc = amt_launch_layernorm(y, x, P(L_N3W), P(L_N3B), nullptr, nullptr, u, 1, E, 1e-5f, s))) return rc;
+        float* tmp = x; x = u; u = tmp;
+    }
+    if ((rc = amt_launch_layernorm(x, nullptr, G(G_FNW), G(G_FNB), nullptr, nullptr, y, 1, E, 1e-5f, s))) return rc;
+    return lin(y, G(G_WOUT), G(G_BOUT), nullptr, logits_out, 159, E, s);
+}

@@ -570,7 +570,84 @@ class VideoMusicTransformer_V2(nn.Module):
             v = ops.linear(memory, W[2 * E:], b[2 * E:])
             st["cross"].append((k, v))
             st["self"].append((torch.empty(self.max_seq_video, E, device=dev), torch.empty(self.max_seq_video, E, device=dev)))
+        # pointer table of amt_v2_step (include/amt_hip.h); `keep` holds every tensor the table points into
+        keep, ptrs = [], []
+
+        def add(t):
+            if t is None:
+                ptrs.append(None)
+            else:
+                t = t.detach().contiguous()
+                keep.append(t)
+                ptrs.append(t.data_ptr())
+
+        def packed(w, rows=None):
+            """Weight (N, K) [or its first `rows` rows] in the skinny GEMM's tile order; packed once per parameter version."""
+            w = w.detach()
+            sig = (w.data_ptr(), w._version, rows)
+            cache = self.__dict__.setdefault("_pack_cache", {})
+            if sig not in cache:
+                src = (w if rows is None else w[:rows]).contiguous()
+                N, K = src.shape
+                out = torch.empty((N + 15) // 16 * 16 * K, device=dev, dtype=torch.float32)
+                _lib.call("amt_pack_weight_fwd", _lib.ptr(src), _lib.ptr(out), N, K, _lib.stream_ptr())
+                cache[sig] = out
+            return cache[sig]
+
+        def packed_experts(experts, name):
+            sig = tuple((getattr(e, name).weight.data_ptr(), getattr(e, name).weight._version) for e in experts) + (name,)
+            cache = self.__dict__.setdefault("_pack_cache", {})
+            if sig not in cache:
+                cache[sig] = torch.cat([packed(getattr(e, name).weight) for e in experts])
+            return cache[sig]
+
+        for t in (self._PR, self._PA, self._wkey, self.Linear_chord.bias, self._rope_cache, self.transformer.decoder.norm.weight,
+                  self.transformer.decoder.norm.bias, packed(self.Wout.weight), self.Wout.bias,
+                  torch.tensor([0, 1], device=dev, dtype=torch.int32)):
+            add(t)
+        from .moe import GLUExpert, _stack
+        dff = None
+        for lyr, (kc, vc), (kx, vx) in zip(self.transformer.decoder.layers, st["self"], st["cross"]):
+            sa, ca = lyr.self_attn, lyr.cross_attn
+            for t in (packed(sa.in_proj_weight), sa.in_proj_bias, packed(sa.out_proj.weight), sa.out_proj.bias, lyr.norm1.weight, lyr.norm1.bias,
+                      packed(ca.in_proj_weight, rows=E), ca.in_proj_bias, packed(ca.out_proj.weight), ca.out_proj.bias, lyr.norm2.weight,
+                      lyr.norm2.bias, lyr.norm3.weight, lyr.norm3.bias, kc, vc, kx, vx):
+                add(t)
+            ff = lyr.ff
+            if isinstance(ff, GLUExpert):
+                dff = ff.linear1.out_features
+                for t in (None, None, packed(ff.linear1.weight), ff.linear1.bias, packed(ff.gate.weight), ff.gate.bias,
+                          packed(ff.linear2.weight), ff.linear2.bias):
+                    add(t)
+                for _ in range(6):
+                    add(None)
+            else:
+                if ff.n_experts_per_token != 2 or getattr(ff, "expert_parallel", False):
+                    raise NotImplementedError("the cached V2 step is built for local top-2 MoE layers")
+                dff = ff.experts[0].linear1.out_features
+                add(ff.gate.weight), add(ff.gate.bias)
+                for name in ("linear1", "gate", "linear2"):
+                    add(packed_experts(ff.experts, name))
+                    add(_stack(ff.experts, name, "bias"))
+                e = ff.shared_expert if ff.shared else None
+                if e is None:
+                    for _ in range(6):
+                        add(None)
+                else:
+                    for t in (packed(e.linear1.weight), e.linear1.bias, packed(e.gate.weight), e.gate.bias, packed(e.linear2.weight), e.linear2.bias):
+                        add(t)
+        st["tab"] = (C.c_void_p * len(ptrs))(*ptrs)
+        st["keep"] = keep
+        st["dff"] = dff
+        st["ws"] = torch.empty(_lib.call("amt_v2_step_ws_floats", E, dff, self.n_experts), device=dev, dtype=torch.float32)
+        st["logits"] = torch.empty(CHORD_SIZE, device=dev, dtype=torch.float32)
         return st
+
+    def _decode_step_native(self, root, attr, key, t, st):
+        """`_decode_step` issued by one library call (amt_v2_step): logits (159,) for input position t."""
+        _lib.call("amt_v2_step", st["tab"], self.nlayers, self.nhead, self.d_model, st["dff"], self.n_experts, st["S"], int(t),
+                  int(root), int(attr), float(key), _lib.ptr(st["logits"]), _lib.ptr(st["ws"]), _lib.stream_ptr())
+        return st["logits"]
 
     def _decode_step(self, root_t, attr_t, key, t, st):
         """Logits (159,) for input position t given the cached positions < t (appends position t to the caches)."""
@@ -633,13 +710,13 @@ class VideoMusicTransformer_V2(nn.Module):
         if T > self.max_seq_video:
             raise ValueError(f"chord sequence longer than the RoPE cache ({self.max_seq_video}), like in the reference")
         if use_cache:
-            dev_key = feature_key.to(device=dev, dtype=torch.float32).reshape(-1)[:1].contiguous()
+            key_val = float(feature_key.reshape(-1)[0])
             st = self._cache_init(memory, S)
             for t in range(P - 1):          # primer positions whose logits are not needed: fill the caches
-                self._decode_step(gen_root[:, t:t + 1].to(dev), gen_attr[:, t:t + 1].to(dev), dev_key, t, st)
+                self._decode_step_native(gen_root[0, t], gen_attr[0, t], key_val, t, st)
         while cur < T:
             if use_cache:
-                row = self._decode_step(gen_root[:, cur - 1:cur].to(dev), gen_attr[:, cur - 1:cur].to(dev), dev_key, cur - 1, st).cpu()
+                row = self._decode_step_native(gen_root[0, cur - 1], gen_attr[0, cur - 1], key_val, cur - 1, st).cpu()
             else:
                 row = self._decode(gen_root[:, :cur], gen_attr[:, :cur], feature_key, memory, B, S)[0, cur - 1].cpu()
             probs = torch.softmax(row / temperature, dim=-1)[:CHORD_END]
