@@ -82,6 +82,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its bundled HIP runtime must be the one in the process before the extension is mapped, or the
+    # extension binds to /opt/rocm's copy and the two runtimes do not see each other's device state
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise AmtError(f"{LIB_PATH} is missing: the HIP extension is not built (run __graft_entry__.build()); "
                        "video2music_amd has no CPU fallback")
