@@ -146,6 +146,21 @@ def test_top1_branch_in_one_pass_equals_the_step_loop(model1):
     assert a.shape == (4, 80) and torch.equal(a, b) and torch.equal(a[:, :3].cpu(), prim[:, :, 0])
 
 
+def test_shapes_outside_the_fold_fall_back_to_the_plain_chain():
+    """dim_feedforward + d_model > 1536 does not fit the folded skinny GEMM (K <= 1536): the handle silently uses the
+    plain 49-launch chain; ids still equal the oracle's."""
+    cfg = dict(CFG1, dim_feedforward=1536)
+    m, sd = build(cfg, seed=4)
+    fc = feats_t(synthetic.synthetic_features(1, seed=8))
+    f = cu(fc)
+    pr, prr, pra = (torch.tensor([v]) for v in C.primer_from_name("C"))
+    out = m.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], pr, prr, pra,
+                           target_seq_length=20, beam=0, sampler="argmax")
+    ref = O.generate(sd, cfg["num_heads"], fc["semantic"], fc["key"], fc["scene_offset"], fc["motion"], fc["emotion"],
+                     pr, prr, pra, target_seq_length=20, beam=0)
+    assert torch.equal(out.cpu(), ref)
+
+
 def test_sampled_generate_is_valid_and_seeded(model1):
     m, _ = model1
     f = cu(feats_t(synthetic.synthetic_features(2, seed=5)))
