@@ -41,6 +41,26 @@ def default_primer(feature_key):
     return C.primer_from_name("C" if int(feature_key) == 0 else "A:min")
 
 
+def regression_levels(args, f, device):
+    """generate.py:394-409 / video2music.py:849-865: the regression head on (semantic, emotion); per frame the integer
+    note density (round, clip [0,40]) and loudness level (int(100 x), clip [0,50]) the MIDI renderer consumes."""
+    from .model.video_regression import VideoRegression
+    reg = VideoRegression(n_layers=args.n_layers_reg, d_model=args.d_model_reg, d_hidden=args.dim_feedforward_reg,
+                          max_sequence_video=args.max_sequence_video, total_vf_dim=f["semantic"].shape[-1] + f["emotion"].shape[-1],
+                          regModel=args.regModel).eval()
+    if args.synthetic or args.synthetic_weights:
+        shapes = [(k, tuple(v.shape)) for k, v in reg.state_dict().items()]
+        reg.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=1).items()})
+    else:
+        reg.load_state_dict(torch.load(args.modelReg_weights, map_location="cpu"))
+    reg = reg.to(device)
+    ln_nd, _ = reg(f["semantic"], f["scene_offset"], f["motion"], f["emotion"])
+    y = ln_nd.cpu().numpy()
+    nd = np.clip(np.round(y[..., 0]).astype(int), 0, 40)
+    lv = np.clip((y[..., 1] * 100).astype(int), 0, 50)
+    return list(zip(nd, lv))
+
+
 def main(argv=None):
     args = parse_generate_args(argv)[0]
     if args.music_gen_version in ("None", "none", ""):
@@ -106,12 +126,20 @@ def main(argv=None):
                                            sampler=args.sampler))
             toks = torch.cat(rows) if rows else torch.empty(0, args.target_seq_length_chord, dtype=torch.long, device=device)
         toks = vdist.all_gather_sequences(toks, args.n_clips)
+        reg_rows = None
+        if args.regression:
+            reg_rows = regression_levels(args, f, device)
     if rank == 0:
         os.makedirs(args.output_dir, exist_ok=True)
         out = toks.cpu().numpy()
         from .dataset.vevo_features import write_lab
         for name, row in zip(names, out):
             write_lab(os.path.join(args.output_dir, f"{name}_chords.lab"), row)      # generate.py:440-444
+        if reg_rows is not None:            # this rank's clips only (the head is cheap; no gather)
+            for name, (nd, lv) in zip(names[lo:hi], reg_rows):
+                with open(os.path.join(args.output_dir, f"{name}_loudness_density.csv"), "w") as fh:
+                    fh.write("frame,note_density,loudness_level\n")
+                    fh.write("".join(f"{i},{int(a)},{int(b)}\n" for i, (a, b) in enumerate(zip(nd, lv))))
         print(json.dumps({"clips": int(out.shape[0]), "length": int(out.shape[1]), "first": out[0, :16].tolist()}))
     return toks
 

@@ -34,6 +34,12 @@ def parse_generate_args(argv=None):
     parser.add_argument("-emo_model", type=str, default="6c_l14p")
     parser.add_argument("-motion_type", type=int, default=1, help="0 as original, 1 as option 1, 2 as option 2")
     parser.add_argument("-rpr", type=bool, default=RPR)
+    # regression head (argument_generate_funcs.py:64,87-91)
+    parser.add_argument("-modelReg_weights", type=str, default="saved_models/AMT/best_rmse_weights.pickle")
+    parser.add_argument("-n_layers_reg", type=int, default=6)
+    parser.add_argument("-d_model_reg", type=int, default=128)
+    parser.add_argument("-dim_feedforward_reg", type=int, default=256)
+    parser.add_argument("-regModel", type=str, default="bimamba+")
     # additions of this build
     parser.add_argument("--synthetic", action="store_true", help="random-init procedural weights and random video features")
     parser.add_argument("--n_clips", type=int, default=1, help="clips to generate for (sharded over ranks under torchrun)")
@@ -41,6 +47,8 @@ def parse_generate_args(argv=None):
                         help="clip ids to read from -dataset_dir, comma separated, or split:<name> for vevo_meta/split/v1/<name>.txt "
                              "(the reference hard-codes one test_id at generate.py:29)")
     parser.add_argument("--synthetic_weights", action="store_true", help="random-init procedural weights with real feature files")
+    parser.add_argument("--regression", action="store_true",
+                        help="also run the VideoRegression head and write <id>_loudness_density.csv (generate.py:394-409)")
     parser.add_argument("--sampler", type=str, default="categorical", choices=["categorical", "argmax"])
     parser.add_argument("--seed", type=int, default=1234)
     return parser.parse_known_args(argv)
