@@ -159,6 +159,27 @@ int32_t amt_attn_decode_fwd(const float* q, const float* kcache, const float* vc
 int32_t amt_decode_linear_fwd(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b,
                               const float* resid, float* y, float* xn_out, float* w_packed_scratch,
                               int32_t B, int32_t N, int32_t K, int32_t relu, float eps, void* stream);
+/* The two kernels of the decode step in the form the handle uses them, with a LayerNorm folded through the projection
+ * (reference rpr.py:59-69 computes LayerNorm(u) then the projection):
+ * amt_attn_decode_fold_fwd: raw (B, ldq) = u . (W o gamma)^T, columns [0,d) query (and [d,2d) key, [2d,3d) value of the new
+ *   position when new_kv = 1); u (B, d) the pre-LayerNorm sum; q = ((raw - mu*fold_g) * rstd + fold_c) * q_scale with the row
+ *   statistics of u; xn_out (optional) = LayerNorm(u).  new_kv = 1 also writes the key/value of position *pos_dev into the
+ *   caches and attends keys 0..pos; new_kv = 0 attends keys 0..n_keys-1 (cross-attention).
+ * amt_decode_gemm_ex_fwd: rows [x (K1 columns) | x2 (K-K1 columns)]; y_low (B, n_low) = act(x . w_low^T + b (+resid)) over the
+ *   first K1 columns (all K when x2 is null), y_high (B, n_high) = [x|x2] . w_high^T + b_high.  pro = 1: the staged row is
+ *   [relu((x - mu*fold_g)*rstd + fold_c) | LayerNorm(x2)] (statistics of x2's row) and LayerNorm(x2) is y_low's residual.
+ *   Weights are given in nn.Linear layout and packed into the scratch buffers (ceil(n/16)*16*K floats each). */
+int32_t amt_attn_decode_fold_fwd(const float* raw, int32_t ldq, float* kcache, float* vcache, const float* Er,
+                                 const float* u, const float* fold_g, const float* fold_c, const float* ln_w,
+                                 const float* ln_b, float* xn_out, float* o, int32_t B, int32_t H, int32_t hd,
+                                 int32_t cap, const int32_t* pos_dev, int32_t n_keys, int32_t er_len, int32_t new_kv,
+                                 float eps, float q_scale, void* stream);
+int32_t amt_decode_gemm_ex_fwd(const float* x, int32_t ldx, const float* x2, int32_t ldx2, int32_t K1, int32_t K,
+                               const float* w_low, const float* bias_low, const float* resid, int32_t relu,
+                               const float* w_high, const float* bias_high, int32_t n_low, int32_t n_high,
+                               int32_t pro, const float* fold_g, const float* fold_c, const float* ln_w, const float* ln_b,
+                               float* y_low, float* y_high, float* scratch_low, float* scratch_high,
+                               int32_t B, float eps, void* stream);
 /* MultiheadGQA.forward (grouped_query_attention.py:286-358) without RoPE: query/key/value are the
  * caller's (L,B,E) buffers, weights in nn.Linear layout; scratch >= 4*L*B*E floats. */
 int32_t amt_gqa_fwd(const float* query, const float* key, const float* value,

@@ -241,3 +241,107 @@ def test_attention_decode_random_sweep():
                   er_len if rpr else 0, sp())
         err = (o.cpu().double() - ref).abs().max().item()
         assert err < 3e-5, (case, B, H, hd, cap, pos, rpr, err)
+
+
+def _ln64(x, w, b, eps=1e-5):
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * w + b, mu, 1.0 / torch.sqrt(var + eps)
+
+
+def test_folded_decode_attention_random_sweep():
+    """attn_decode with the LayerNorm folded through the query (and new key/value) projection, against the unfolded
+    arithmetic in fp64: q = (LN(u) W^T + b) * scale with W' = W o gamma, g = rowsum(W'), c = W beta + b."""
+    rs = np.random.RandomState(5)
+    for case in range(16):
+        hd = int(rs.choice([32, 64, 128]))
+        H = int(rs.choice([1, 4, 8]))
+        d = H * hd
+        if d > 1024:
+            continue
+        B = int(rs.randint(1, 33))
+        cap = int(rs.randint(2, 300))
+        new_kv = case % 2
+        rpr = bool((case // 2) % 2) and new_kv
+        t = int(rs.randint(0, cap))
+        n_out = 3 * d if new_kv else d
+        u = rnd(rs, B, d) + float(rs.uniform(-2, 2))                       # a mean far from 0 stresses the cancellation
+        gam, bet = 1 + rnd(rs, d, scale=0.2), rnd(rs, d, scale=0.1)
+        W, bW = rnd(rs, n_out, d, scale=d ** -0.5), rnd(rs, n_out, scale=0.1)
+        kc, vc = rnd(rs, B, H, cap, hd), rnd(rs, B, H, cap, hd)
+        er_len = cap + 3
+        Er = torch.from_numpy(rs.uniform(size=(er_len, hd)).astype(np.float32))
+        scale = hd ** -0.5
+        # producer side (fp64 here): raw = u (W o gamma)^T ; vectors g, c
+        Wp = W.double() * gam.double()
+        raw = (u.double() @ Wp.t()).float()
+        g, c = Wp.sum(1).float(), (W.double() @ bet.double() + bW.double()).float()
+        # reference
+        xn, _, _ = _ln64(u.double(), gam.double(), bet.double())
+        proj = xn @ W.double().t() + bW.double()
+        q = (proj[:, :d] * scale).view(B, H, 1, hd)
+        K, V = kc.double().clone(), vc.double().clone()
+        n_keys = t + 1 if new_kv else int(rs.randint(1, cap + 1))
+        if new_kv:
+            K[:, :, t], V[:, :, t] = proj[:, d:2 * d].view(B, H, hd), proj[:, 2 * d:].view(B, H, hd)
+        s = q @ K[:, :, :n_keys].transpose(-1, -2)
+        if rpr:
+            idx = er_len - 1 - (t - torch.arange(n_keys))
+            s = s + torch.einsum("bhqd,jd->bhqj", q, Er[idx].double())
+        ref = (torch.softmax(s, -1) @ V[:, :, :n_keys]).reshape(B, d)
+        dk, dv = dev(kc), dev(vc)
+        o, xo = torch.empty(B, d, device="cuda"), torch.empty(B, d, device="cuda")
+        pos = torch.tensor([t], dtype=torch.int32, device="cuda")
+        d_raw, d_er, d_u, d_g, d_c, d_gam, d_bet = (dev(v) for v in (raw, Er, u, g, c, gam, bet))    # keep the device copies alive
+        _lib.call("amt_attn_decode_fold_fwd", _lib.ptr(d_raw), n_out, _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(d_er) if rpr else None,
+                  _lib.ptr(d_u), _lib.ptr(d_g), _lib.ptr(d_c), _lib.ptr(d_gam), _lib.ptr(d_bet), _lib.ptr(xo), _lib.ptr(o),
+                  B, H, hd, cap, _lib.ptr(pos) if new_kv else None, n_keys, er_len if rpr else 0, new_kv, 1e-5, scale, sp())
+        tag = (case, B, H, hd, cap, t, new_kv, rpr)
+        assert (o.cpu().double() - ref).abs().max().item() < 5e-5, tag
+        assert (xo.cpu().double() - xn).abs().max().item() < 2e-5, tag
+        if new_kv:
+            assert (dk.cpu().double()[:, :, t] - K[:, :, t]).abs().max().item() < 3e-5, tag
+            assert (dv.cpu().double()[:, :, t] - V[:, :, t]).abs().max().item() < 3e-5, tag
+            keep = torch.ones(cap, dtype=torch.bool)
+            keep[t] = False
+            assert torch.equal(dk.cpu()[:, :, keep], kc[:, :, keep])             # only row t of the cache is touched
+
+
+def test_skinny_gemm_two_sources_split_and_folded_ffn_prologue():
+    """decode_gemm in the three forms of the folded decode chain (G1/G2: two-source rows + column split; G3: folded-FFN
+    prologue) against fp64, incl. ragged batch sizes and K = 1536."""
+    rs = np.random.RandomState(11)
+    for (B, K1, K2, n_low, n_high, pro) in ((32, 512, 512, 512, 512, 0), (7, 128, 128, 128, 256, 0), (32, 1024, 512, 512, 1536, 1),
+                                            (19, 256, 128, 128, 384, 1), (5, 256, 128, 128, 0, 1), (32, 1024, 512, 512, 160, 1)):
+        K = K1 + K2
+        x, x2 = rnd(rs, B, K1), rnd(rs, B, K2) + (0.7 if pro else 0.0)
+        wl, bl = rnd(rs, n_low, K1, scale=K1 ** -0.5), rnd(rs, n_low, scale=0.1)
+        wh, bh = (rnd(rs, n_high, K, scale=K ** -0.5), rnd(rs, n_high, scale=0.1)) if n_high else (None, None)
+        fg, fc = rnd(rs, K1), rnd(rs, K1, scale=0.3)
+        gam, bet = 1 + rnd(rs, K2, scale=0.2), rnd(rs, K2, scale=0.1)
+        if pro:
+            ln, mu, rstd = _ln64(x2.double(), gam.double(), bet.double())
+            a = torch.relu((x.double() - mu * fg.double()) * rstd + fc.double())
+            rows = torch.cat([a, ln], 1)
+            ref_low = a @ wl.double().t() + bl.double() + ln[:, :n_low]
+            resid = None
+        else:
+            rows = torch.cat([x.double(), x2.double()], 1)
+            resid = x2[:, :n_low].contiguous() if K2 >= n_low else None
+            ref_low = x.double() @ wl.double().t() + bl.double() + (resid.double() if resid is not None else 0)
+        ref_high = rows @ wh.double().t() + bh.double() if n_high else None
+        yl = torch.empty(B, n_low, device="cuda")
+        yh = torch.empty(B, max(n_high, 1), device="cuda")
+        sl = torch.empty((n_low + 15) // 16 * 16 * K1, device="cuda")
+        sh = torch.empty(max((n_high + 15) // 16 * 16 * K, 1), device="cuda")
+        D = {k: dev(v) for k, v in dict(x=x, x2=x2, wl=wl, bl=bl, fg=fg, fc=fc, gam=gam, bet=bet).items()}    # keep the device copies alive
+        for k, v in dict(resid=resid, wh=wh, bh=bh).items():
+            D[k] = dev(v) if v is not None else None
+        P = lambda k, on=True: _lib.ptr(D[k]) if on and D[k] is not None else None
+        _lib.call("amt_decode_gemm_ex_fwd", P("x"), K1, P("x2"), K2, K1, K, P("wl"), P("bl"), P("resid"), 0, P("wh"), P("bh"), n_low, n_high, pro,
+                  P("fg", pro), P("fc", pro), P("gam", pro), P("bet", pro), _lib.ptr(yl), _lib.ptr(yh) if n_high else None,
+                  _lib.ptr(sl), _lib.ptr(sh) if n_high else None, B, 1e-5, sp())
+        tag = (B, K1, K2, n_low, n_high, pro)
+        assert (yl.cpu().double() - ref_low).abs().max().item() < 3e-5, tag
+        if n_high:
+            assert (yh.cpu().double() - ref_high).abs().max().item() < 3e-5, tag

@@ -55,6 +55,8 @@ SIGNATURES = {
     "amt_chord_embed_fwd": [_P] * 9 + [_I, _I, _I, _P],
     "amt_attn_decode_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "amt_decode_linear_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "amt_attn_decode_fold_fwd": [_P, _I] + [_P] * 10 + [_I, _I, _I, _I, _P, _I, _I, _I, _F, _F, _P],
+    "amt_decode_gemm_ex_fwd": [_P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P],
     "amt_gqa_fwd": [_P] * 15 + [_I] * 7 + [_F, _P],
     "amt_moe_scratch_floats": [_I, _I, _I, _I],
     "amt_moe_fwd": [_P] * 19 + [_I] * 4 + [_P],

@@ -997,6 +997,43 @@ extern "C" int32_t amt_attn_decode_fwd(const float* q, const float* kcache, cons
     return amt_launch_attn_decode(a, (hipStream_t)stream);
 }
 
+extern "C" int32_t amt_attn_decode_fold_fwd(const float* raw, int32_t ldq, float* kcache, float* vcache, const float* Er,
+                                            const float* u, const float* fold_g, const float* fold_c, const float* ln_w,
+                                            const float* ln_b, float* xn_out, float* o, int32_t B, int32_t H, int32_t hd,
+                                            int32_t cap, const int32_t* pos_dev, int32_t n_keys, int32_t er_len, int32_t new_kv,
+                                            float eps, float q_scale, void* stream) {
+    AMT_CHECK_ARG(raw && kcache && vcache && u && fold_g && fold_c && o, "amt_attn_decode_fold_fwd: null pointer");
+    AMT_CHECK_ARG(pos_dev || (!new_kv && n_keys > 0 && n_keys <= cap), "amt_attn_decode_fold_fwd: need a device position or a key count");
+    AttnDecodeParams a{};
+    a.q = raw; a.ldq = ldq; a.k = kcache; a.v = vcache; a.o = o; a.B = B; a.H = H; a.hd = hd; a.cap = cap; a.d = H * hd;
+    a.pos = (const int*)pos_dev; a.n_keys = n_keys; a.Er = Er; a.er_len = er_len;
+    a.fold_u = u; a.fold_g = fold_g; a.fold_c = fold_c; a.fold_lnw = ln_w; a.fold_lnb = ln_b; a.xn = xn_out;
+    a.new_kv = new_kv; a.k_new = kcache; a.v_new = vcache; a.eps = eps; a.q_scale = q_scale;
+    return amt_launch_attn_decode(a, (hipStream_t)stream);
+}
+
+extern "C" int32_t amt_decode_gemm_ex_fwd(const float* x, int32_t ldx, const float* x2, int32_t ldx2, int32_t K1, int32_t K,
+                                          const float* w_low, const float* bias_low, const float* resid, int32_t relu,
+                                          const float* w_high, const float* bias_high, int32_t n_low, int32_t n_high,
+                                          int32_t pro, const float* fold_g, const float* fold_c, const float* ln_w, const float* ln_b,
+                                          float* y_low, float* y_high, float* scratch_low, float* scratch_high,
+                                          int32_t B, float eps, void* stream) {
+    AMT_CHECK_ARG(x && w_low && y_low && scratch_low && n_low > 0 && n_low % 16 == 0, "amt_decode_gemm_ex_fwd: bad low part");
+    AMT_CHECK_ARG(n_high == 0 || (w_high && y_high && scratch_high && x2), "amt_decode_gemm_ex_fwd: incomplete high part");
+    hipStream_t s = (hipStream_t)stream;
+    const int Klow = x2 ? K1 : K;
+    int32_t rc;
+    if ((rc = amt_launch_pack_weight(w_low, scratch_low, n_low, Klow, s))) return rc;
+    if (n_high > 0 && (rc = amt_launch_pack_weight(w_high, scratch_high, n_high, K, s))) return rc;
+    DecodeGemmParams g{};
+    g.B = B; g.eps = eps; g.scale = 1.f; g.x = x; g.ldx = ldx; g.x2 = x2; g.ldx2 = ldx2; g.K1 = K1; g.K = K;
+    g.Wp = scratch_low; g.bias = bias_low; g.resid = resid; g.ldr = n_low; g.relu = relu; g.y = y_low; g.ldy = n_low;
+    g.pro = pro; g.fold_g = fold_g; g.fold_c = fold_c; g.ln_w = ln_w; g.ln_b = ln_b;
+    g.N = n_low + n_high;
+    if (x2) { g.n_split = n_low; g.Wp2 = scratch_high; g.bias2 = bias_high; g.y2 = y_high; g.ldy2 = n_high; }
+    return amt_launch_decode_gemm(g, s);
+}
+
 extern "C" int32_t amt_decode_linear_fwd(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b,
                                          const float* resid, float* y, float* xn_out, float* w_packed_scratch,
                                          int32_t B, int32_t N, int32_t K, int32_t relu, float eps, void* stream) {
