@@ -117,10 +117,11 @@ def test_generate_cli_reads_feature_files_and_writes_lab(tmp_path):
     write_mini_dataset(root, mini_dataset_content(seed=11))
     argv = ["-dataset_dir", root, "-output_dir", out, "--test_ids", "split:test", "--synthetic_weights", "-music_gen_version", "None",
             "-n_layers", "2", "-num_heads", "4", "-d_model", "128", "-dim_feedforward", "256", "-target_seq_length_chord", "24",
-            "-max_sequence_chord", "300", "--sampler", "argmax", "-motion_type", "1", "--regression", "-n_layers_reg", "2",
+            "-max_sequence_chord", "300", "--sampler", "argmax", "-motion_type", "1", "--regression", "--midi", "-n_layers_reg", "2",
             "-d_model_reg", "32", "-dim_feedforward_reg", "64"]
     toks = G.main(argv).cpu()
     assert toks.shape == (2, 24)
+    assert open(os.path.join(out, "003_chords.mid"), "rb").read(4) == b"MThd"
     rows = open(os.path.join(out, "017_loudness_density.csv")).read().splitlines()
     assert rows[0] == "frame,note_density,loudness_level" and len(rows) == 301 and all(0 <= int(r.split(",")[2]) <= 50 for r in rows[1:])
     for i, fid in enumerate(("003", "017")):

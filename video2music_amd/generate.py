@@ -3,8 +3,8 @@
 Reproduces the part of the reference script that feeds ``model.generate``: flag names/defaults
 (``parse_generate_args``), the ``total_vf_dim`` rule (:141-160), the batch-1 feature shapes
 (:181-189), the key rule (:199-207), the default primer ("C" / "A:min", :246-284) and the
-``model.generate`` keyword names (:368-392) and the chord ``.lab`` it writes (:440-444).  The rest of what follows
-the chord ids (regression model, MIDI voicing, FluidSynth, moviepy: :393-709) is out of scope.  Inputs come from
+``model.generate`` keyword names (:368-392), the chord ``.lab`` it writes (:440-444), and with ``--regression`` / ``--midi`` the
+regression head and the voiced-arpeggio MIDI (:393-607).  Audio and video rendering (FluidSynth, moviepy: :608-709) are out of scope.  Inputs come from
 ``--synthetic`` or from MuVi-Sync feature files (``-dataset_dir`` + ``--test_ids``, ``dataset/vevo_features.py``); under torchrun the clips are sharded over ranks and the ids all-gathered.
 
     python -m video2music_amd.generate --synthetic --n_clips 4 -target_seq_length_chord 64 -beam 0
@@ -135,6 +135,14 @@ def main(argv=None):
         from .dataset.vevo_features import write_lab
         for name, row in zip(names, out):
             write_lab(os.path.join(args.output_dir, f"{name}_chords.lab"), row)      # generate.py:440-444
+        if args.midi:
+            from .render import chord_midi
+            for i, (name, row) in enumerate(zip(names, out)):
+                levels = None
+                if reg_rows is not None and lo <= i < hi:
+                    lv = reg_rows[i - lo][1]
+                    levels = [int(lv[min(j, len(lv) - 1)]) for j in range(len(row))]
+                chord_midi.write_midi(os.path.join(args.output_dir, f"{name}_chords.mid"), chord_midi.arrange(row, levels))
         if reg_rows is not None:            # this rank's clips only (the head is cheap; no gather)
             for name, (nd, lv) in zip(names[lo:hi], reg_rows):
                 with open(os.path.join(args.output_dir, f"{name}_loudness_density.csv"), "w") as fh:

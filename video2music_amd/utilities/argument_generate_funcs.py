@@ -49,6 +49,9 @@ def parse_generate_args(argv=None):
     parser.add_argument("--synthetic_weights", action="store_true", help="random-init procedural weights with real feature files")
     parser.add_argument("--regression", action="store_true",
                         help="also run the VideoRegression head and write <id>_loudness_density.csv (generate.py:394-409)")
+    parser.add_argument("--midi", action="store_true",
+                        help="also write <id>_chords.mid (voiced arpeggios, velocities from the regression head when --regression is set; "
+                             "generate.py:446-607)")
     parser.add_argument("--sampler", type=str, default="categorical", choices=["categorical", "argmax"])
     parser.add_argument("--seed", type=int, default=1234)
     return parser.parse_known_args(argv)
