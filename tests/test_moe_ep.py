@@ -82,7 +82,7 @@ ref = layer(x).clone()
 layer.enable_expert_parallel()
 got = layer(x)
 err = (got - ref).abs().max().item()
-assert err < 1e-6, (rank, err)
+assert err < 2e-5, (rank, err)      # the small per-rank shards run on the skinny GEMM, the full layer on the grouped one: summation order differs
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok", err)
 """

@@ -19,7 +19,7 @@
 
 namespace {
 
-constexpr int MAXB = 32;
+constexpr int MAXB = 4096;       // rows per launch (16 per workgroup, blockIdx.y); the decode step uses 32
 constexpr int XPAD = 8;
 
 __global__ void pack_weight_kernel(const float* __restrict__ W, float* __restrict__ P, int N, int K) {
@@ -105,8 +105,14 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
     float4 wt[KCH];
     const int grp = p.sel ? *p.sel : 0;             // device-chosen weight group (mixture-of-experts, one token)
     const float* wbase = high ? p.Wp2 + (size_t)(nt - nts) * kt_n * 256 : p.Wp + (size_t)grp * p.sel_w_stride + (size_t)nt * kt_n * 256;
+    // un-packed weights (ldw > 0): lane (n = lane & 15, k-quad = lane >> 4) reads its float4 of row n directly: 16 rows x 64 B
+    // per tile instead of one 1 KiB run, still one fully used 64-B segment per row
+    const float* wrow = p.Wp + (size_t)min(nt * 16 + (lane & 15), p.N - 1) * p.ldw + 4 * (lane >> 4);
 #pragma unroll
-    for (int i = 0; i < KCH; ++i) wt[i] = ld4(wbase + ((size_t)min(kt0 + i, kt_n - 1) * 64 + lane) * 4);
+    for (int i = 0; i < KCH; ++i) {
+        const int kt = min(kt0 + i, kt_n - 1);
+        wt[i] = ld4(p.ldw ? wrow + (size_t)kt * 16 : wbase + ((size_t)kt * 64 + lane) * 4);
+    }
     __builtin_amdgcn_sched_barrier(0);              // the scheduler must not sink any of these loads below this point
     const int el = tid & 63, er = (tid >> 6) & 3;
     const int row = m0 + 4 * (el >> 4) + er, n = nt * 16 + (el & 15);
@@ -296,6 +302,7 @@ int32_t amt_launch_decode_gemm(const DecodeGemmParams& p_in, hipStream_t stream)
     if (p.n_split) AMT_CHECK_ARG(p.x2 && p.n_split % 16 == 0 && p.n_split <= p.N && p.mode == 0 && (p.n_split == p.N || (p.Wp2 && p.y2)),
                                  "decode_gemm: bad column split %d of N=%d", p.n_split, p.N);
     AMT_CHECK_ARG(!p.sel || p.n_split == 0, "decode_gemm: a device-selected weight group cannot be combined with a column split");
+    AMT_CHECK_ARG(p.ldw == 0 || (p.ldw >= p.K && p.ldw % 4 == 0 && p.n_split == 0 && !p.sel), "decode_gemm: bad un-packed weight (ldw=%d)", p.ldw);
     if (p.pro == 1) AMT_CHECK_ARG(p.x2 && p.fold_g && p.fold_c && p.ln_w && p.ln_b && !p.resid, "decode_gemm: incomplete folded-FFN prologue");
     else AMT_CHECK_ARG(!p.ln_w || (!p.x2 && p.K <= 1024), "decode_gemm: the LayerNorm prologue takes a single source of K <= 1024");
     size_t lds = (size_t)MT * (p.K + XPAD) * sizeof(float);

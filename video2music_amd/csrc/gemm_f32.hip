@@ -10,6 +10,8 @@
 // a ds_read_b128 lane group touches 16 distinct 16-B bank slots).  One ds_read_b128 per operand
 // fragment feeds 4 MFMAs: lane (r, h) holds k = k0+4h+e for e=0..3, MFMA e then sums k0+e (h=0)
 // and k0+4+e (h=1) -- any pairing is legal as long as A and B use the same one.
+#include <stdlib.h>
+
 #include "amt_common.h"
 #include "kernels.h"
 
@@ -208,6 +210,18 @@ int32_t amt_launch_gemm(const GemmParams& p, hipStream_t stream) {
     AMT_CHECK_ARG(p.lda % 4 == 0 && p.ldw % 4 == 0, "gemm: leading dimensions must be multiples of 4 floats");
     AMT_CHECK_ARG(p.lda >= p.K && p.ldw >= p.K, "gemm: leading dimension smaller than K");
     AMT_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0, "gemm: operands must be 16-byte aligned");
+    // Small-M products (one decode row, the 300 frames of one clip, a table) are latency-bound on the 128x128 tiles: a
+    // handful of workgroups, each exposing a full memory latency per K step (65 us for one row at K = 512).  With a plain
+    // epilogue they go to the skinny decode GEMM, which puts all of a workgroup's weight loads in flight at once.
+    static int small_m = -1;
+    if (small_m < 0) { const char* e = getenv("AMT_GEMM_SMALL_M"); small_m = e ? atoi(e) : 384; }
+    if (p.M <= small_m && p.K % 64 == 0 && p.K <= 1536 && !p.head_split && !p.rowadd && !p.silu_mul && !p.sigmoid && !p.tile_group &&
+        !p.a_gather && true) {
+        DecodeGemmParams g{};
+        g.B = p.M; g.eps = 1e-5f; g.x = p.A; g.ldx = p.lda; g.Wp = p.W; g.ldw = p.ldw; g.bias = p.bias; g.N = p.N; g.K = p.K;
+        g.resid = p.resid; g.ldr = p.ldr; g.relu = p.relu; g.scale = p.scale; g.scale_cols = p.scale_cols; g.y = p.C; g.ldy = p.ldc;
+        return amt_launch_decode_gemm(g, stream);
+    }
     const int ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
     hipLaunchKernelGGL(gemm_f32_kernel, dim3(ntiles), dim3(256), 0, stream, p);
     AMT_LAUNCH_CHECK();

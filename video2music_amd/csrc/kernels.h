@@ -117,6 +117,7 @@ struct DecodeGemmParams {
     // weight group chosen on the device (one token of a mixture-of-experts layer): Wp / Wp2-less launches only;
     // the packed weight of group *sel starts sel_w_stride floats further, its bias sel_b_stride floats further
     const int* sel; size_t sel_w_stride; int sel_b_stride;
+    int ldw;                    // > 0: Wp is NOT packed but a plain nn.Linear weight [N][ldw] (small-M products of the dense paths)
     const float* zero;          // set by the launcher: zero words in global memory
 };
 int32_t amt_launch_decode_gemm(const DecodeGemmParams& p, hipStream_t stream);
