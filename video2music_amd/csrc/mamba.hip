@@ -48,28 +48,51 @@ __global__ __launch_bounds__(CPB * N) void selective_scan_kernel(ScanParams p) {
     const int ch = c0 + cl;
     const float A = ch < p.ED ? -__expf(p.A_log[(size_t)ch * N + n]) : 0.f;
     float h = 0.f;
+    // global -> registers -> LDS, one pass ahead: the loads of pass k+1 are in flight while pass k runs its recurrence
+    constexpr int EPT = TCH * CPB / (CPB * N), BPT = TCH * N / (CPB * N);     // staged elements per thread
+    float rx[EPT], rd[EPT], rz[EPT], rB[BPT], rC[BPT];
+    auto fetch = [&](int s0) {
+        const int steps = min(TCH, p.L - s0);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = tid + e * CPB * N, s = i / CPB, cc = i % CPB;
+            const int t = p.reverse ? p.L - 1 - (s0 + s) : s0 + s;
+            const size_t row = (size_t)b * p.L + t;
+            const bool ok = s < steps && c0 + cc < p.ED;
+            rx[e] = ok ? p.x[row * p.ldx + c0 + cc] : 0.f;
+            rd[e] = ok ? p.draw[row * p.ldd + c0 + cc] + p.dt_bias[c0 + cc] : -INFINITY;     // softplus(-inf) = 0: the step is a no-op
+            rz[e] = ok ? p.z[row * p.ldz + c0 + cc] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < BPT; ++e) {
+            const int i = tid + e * CPB * N, s = i / N, nn = i % N;
+            const int t = p.reverse ? p.L - 1 - (s0 + s) : s0 + s;
+            const size_t row = (size_t)b * p.L + t;
+            rB[e] = s < steps ? p.Bm[row * p.ldbc + nn] : 0.f;
+            rC[e] = s < steps ? p.Cm[row * p.ldbc + nn] : 0.f;
+        }
+    };
+    fetch(0);
     for (int s0 = 0; s0 < p.L; s0 += TCH) {
         const int steps = min(TCH, p.L - s0);
         // everything that is not the recurrence itself happens here, in parallel over (step, channel): softplus, SiLU
         // (steps past the end of the sequence are staged as delta = 0, x = 0: they leave h unchanged, so the
         // recurrence below always runs TCH steps and unrolls)
-        for (int i = tid; i < TCH * CPB; i += CPB * N) {
-            const int s = i / CPB, cc = i % CPB;
-            const int t = p.reverse ? p.L - 1 - (s0 + s) : s0 + s;
-            const size_t row = (size_t)b * p.L + t;
-            const bool ok = s < steps && c0 + cc < p.ED;
-            sx[s][cc] = ok ? p.x[row * p.ldx + c0 + cc] : 0.f;
-            sd[s][cc] = ok ? softplus(p.draw[row * p.ldd + c0 + cc] + p.dt_bias[c0 + cc]) : 0.f;
-            sz[s][cc] = ok ? silu(p.z[row * p.ldz + c0 + cc]) : 0.f;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = tid + e * CPB * N, s = i / CPB, cc = i % CPB;
+            sx[s][cc] = rx[e];
+            sd[s][cc] = rd[e] == -INFINITY ? 0.f : softplus(rd[e]);
+            sz[s][cc] = silu(rz[e]);
         }
-        for (int i = tid; i < TCH * N; i += CPB * N) {
-            const int s = i / N, nn = i % N;
-            const int t = p.reverse ? p.L - 1 - (s0 + s) : s0 + s;
-            const size_t row = (size_t)b * p.L + t;
-            sB[s][nn] = s < steps ? p.Bm[row * p.ldbc + nn] : 0.f;
-            sC[s][nn] = s < steps ? p.Cm[row * p.ldbc + nn] : 0.f;
+#pragma unroll
+        for (int e = 0; e < BPT; ++e) {
+            const int i = tid + e * CPB * N, s = i / N, nn = i % N;
+            sB[s][nn] = rB[e];
+            sC[s][nn] = rC[e];
         }
         __syncthreads();
+        if (s0 + TCH < p.L) fetch(s0 + TCH);
         // the recurrence: one FMA on the dependency chain per step; exp / LDS reads of later steps overlap (unrolled)
 #pragma unroll 8
         for (int s = 0; s < TCH; ++s) {
