@@ -161,6 +161,28 @@ def test_shapes_outside_the_fold_fall_back_to_the_plain_chain():
     assert torch.equal(out.cpu(), ref)
 
 
+@pytest.mark.parametrize("d,H,ff", [(256, 2, 512), (256, 8, 256), (192, 3, 320)])
+def test_other_head_sizes_through_the_folded_chain(d, H, ff):
+    """head_dim 128 / 32 / 64 with d_model not a power of two: greedy ids of the folded decode chain equal the oracle's and
+    the decode logits equal the teacher-forced forward."""
+    cfg = dict(CFG1, d_model=d, num_heads=H, dim_feedforward=ff, n_layers=3)
+    m, sd = build(cfg, seed=d + H)
+    fc = feats_t(synthetic.synthetic_features(2, seed=d))
+    f = cu(fc)
+    pr, prr, pra = (torch.tensor([v]) for v in C.primer_from_name("C"))
+    T = 28
+    toks, lg = m.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], pr, prr, pra,
+                                target_seq_length=T, beam=0, sampler="argmax", return_logits=True)
+    one = {k: v[:1] for k, v in fc.items()}
+    ref = O.generate(sd, H, one["semantic"], one["key"], one["scene_offset"], one["motion"], one["emotion"], pr, prr, pra,
+                     target_seq_length=T, beam=0)
+    assert torch.equal(toks[:1].cpu(), ref)
+    roots, attrs = roots_attrs_of(toks.cpu(), int(prr[0]), int(pra[0]))
+    with torch.no_grad():
+        fwd = m(toks, roots.cuda(), attrs.cuda(), f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"])
+    assert (fwd[:, :T - 1].permute(1, 0, 2) - lg[:T - 1]).abs().max().item() < 2e-4
+
+
 def test_sampled_generate_is_valid_and_seeded(model1):
     m, _ = model1
     f = cu(feats_t(synthetic.synthetic_features(2, seed=5)))
