@@ -130,11 +130,25 @@ def roofline(model, f, prim, B, T, cfg):
                           "avg_launch_us": round(avg_us("cross_attn_decode"), 3),
                           "algorithmic_bytes_per_launch": round(st["cross_attn_decode"]["bytes"] / n)},
         "other_kernels_avg_us": {k: round(avg_us(k), 3) for k in ("decode_gemm", "sample")},
+        "whole_step": whole_step(cfg, B, T, st, full),
         "in_situ": {"method": "generate ms minus generate ms with the kernel left out of the step graph, per launch; "
                               "median of 3 interleaved rounds",
                     "generate_ms": {"full": round(full, 2), "without_self_attn": round(no_self, 2), "without_cross_attn": round(no_cross, 2)},
                     "self_attn_us": round(1e3 * (full - no_self) / n, 3), "cross_attn_us": round(1e3 * (full - no_cross) / n, 3)},
     }
+
+
+def whole_step(cfg, B, T, st, generate_ms):
+    """SURVEY.md §8(d) step-level figure: algorithmic bytes of one average decode step (decoder weights read once, the
+    clips' cross-attention K/V, the self-attention K/V at the mean length) over the measured step time."""
+    d, dff, nl, S = cfg["d_model"], cfg["dim_feedforward"], cfg["n_layers"], 300
+    steps = T - 1
+    weights = nl * (8 * d * d + 2 * d * dff) * 4 + (159 * d + (d + 1) * d) * 4
+    kv = (st["self_attn_decode"]["bytes"] + st["cross_attn_decode"]["bytes"]) / steps
+    us = 1e3 * generate_ms / steps
+    return {"algorithmic_bytes_per_step": round(weights + kv), "us_per_step_incl_encode": round(us, 2),
+            "achieved": round((weights + kv) / us / 1e3, 1), "unit": "GB/s", "frac": round((weights + kv) / us / 1e3 / HBM_PEAK_GBS, 4),
+            "note": "31 dependent launches per step: the step is bound by the launch chain, the streaming kernels by HBM"}
 
 
 def main():
