@@ -210,13 +210,19 @@ int32_t amt_launch_gemm(const GemmParams& p, hipStream_t stream) {
     AMT_CHECK_ARG(p.lda % 4 == 0 && p.ldw % 4 == 0, "gemm: leading dimensions must be multiples of 4 floats");
     AMT_CHECK_ARG(p.lda >= p.K && p.ldw >= p.K, "gemm: leading dimension smaller than K");
     AMT_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0, "gemm: operands must be 16-byte aligned");
-    // Small-M products (one decode row, the 300 frames of one clip, a table) are latency-bound on the 128x128 tiles: a
-    // handful of workgroups, each exposing a full memory latency per K step (65 us for one row at K = 512).  With a plain
-    // epilogue they go to the skinny decode GEMM, which puts all of a workgroup's weight loads in flight at once.
-    static int small_m = -1;
-    if (small_m < 0) { const char* e = getenv("AMT_GEMM_SMALL_M"); small_m = e ? atoi(e) : 384; }
-    if (p.M <= small_m && p.K % 64 == 0 && p.K <= 1536 && !p.head_split && !p.rowadd && !p.silu_mul && !p.sigmoid && !p.tile_group &&
-        !p.a_gather && true) {
+    // Small products (one decode row, the 300 frames of one clip, a table, a few thousand rows of a narrow layer): a 128x128
+    // tile costs its full MFMA time on one CU whatever part of it is real rows (27 us at K = 512; ~50 us measured), and with
+    // fewer tiles than CUs nothing hides it.  With a plain epilogue they go to the skinny GEMM (16x16 output tiles, all of a
+    // workgroup's weight loads in flight at once): ~10 us up to M*N = 256k outputs, break-even near 1.3M (tools/bench_small_gemm.py).
+    static long small_m = -1, small_mn = -1;
+    if (small_m < 0) {
+        const char* e = getenv("AMT_GEMM_SMALL_M");
+        small_m = e ? atol(e) : 4096;
+        const char* f = getenv("AMT_GEMM_SMALL_MN");
+        small_mn = f ? atol(f) : 1300000;
+    }
+    if (p.M <= small_m && (long)p.M * p.N <= small_mn && p.K % 64 == 0 && p.K <= 1536 && !p.head_split && !p.rowadd && !p.silu_mul &&
+        !p.sigmoid && !p.tile_group && !p.a_gather) {
         DecodeGemmParams g{};
         g.B = p.M; g.eps = 1e-5f; g.x = p.A; g.ldx = p.lda; g.Wp = p.W; g.ldw = p.ldw; g.bias = p.bias; g.N = p.N; g.K = p.K;
         g.resid = p.resid; g.ldr = p.ldr; g.relu = p.relu; g.scale = p.scale; g.scale_cols = p.scale_cols; g.y = p.C; g.ldy = p.ldc;
