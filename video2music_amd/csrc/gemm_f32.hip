@@ -5,7 +5,8 @@
 // (Linear_vis, packed in-proj, out-proj, FFN, cross K/V projection, Wout).
 //
 // Tiling (gfx950): 128x128 output tile per 256-thread workgroup, 4 waves as 2x2, each wave a
-// 64x64 sub-tile = 2x2 v_mfma_f32_32x32x2_f32 accumulators (exact fp32, k-ordered fma chain).
+// 64x64 sub-tile = 2x2 v_mfma_f32_32x32x2_f32 accumulators (exact fp32, k-ordered fma chain); a 64x64-tile
+// instantiation (one accumulator per wave) serves launches with too few 128x128 tiles to fill the GPU.
 // K is consumed 32 at a time through a double-buffered LDS image [128][36] (row stride 144 B, so
 // a ds_read_b128 lane group touches 16 distinct 16-B bank slots).  One ds_read_b128 per operand
 // fragment feeds 4 MFMAs: lane (r, h) holds k = k0+4h+e for e=0..3, MFMA e then sums k0+e (h=0)
@@ -17,9 +18,9 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, LDS_LD = BK + 4;   // floats
+constexpr int BK = 32, LDS_LD = BK + 4;   // floats
+// TM x TN = 32x32 MFMA tiles per wave (waves 2x2): workgroup tile 64*TM x 64*TN, i.e. 128x128 (2,2) or 64x64 (1,1)
 
-struct Frag4 { float4 v[4]; };
 
 __device__ __forceinline__ void store_out(const GemmParams& p, int row, int col, float v) {
     if (row >= p.M || col >= p.N) return;
@@ -46,8 +47,10 @@ __device__ __forceinline__ void store_out(const GemmParams& p, int row, int col,
     }
 }
 
+template <int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2][BM * LDS_LD];   // [buf][A|W][row][k]
+    constexpr int BM = 64 * TM, BN = 64 * TN, BMAX = BM > BN ? BM : BN;
+    __shared__ __attribute__((aligned(16))) float lds[2][2][BMAX * LDS_LD];   // [buf][A|W][row][k]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 
@@ -68,34 +71,35 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         if (p.bias) p.bias += (size_t)g * p.bias_group_stride;
     }
 
-    // staging: 256 threads x 4 passes x float4 cover a 128x32 tile (8 float4 per row)
+    // staging: 256 threads x (rows/32) passes x float4 cover a rows x 32 tile (8 float4 per row)
     const int srow = tid >> 3, scol = (tid & 7) * 4;
-    Frag4 ra, rw;
+    float4 ra[2 * TM], rw[2 * TN];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int r = srow + i * 32;
-            int gm = m0 + r, gn = n0 + r;
+        for (int i = 0; i < 2 * TM; ++i) {
+            const int gm = m0 + srow + i * 32;
             int am = gm;
             if (p.a_gather) am = (gm < p.M) ? p.a_gather[gm] : -1;
-            ra.v[i] = (gm < p.M && am >= 0) ? ld4(p.A + (size_t)am * p.lda + k0 + scol) : make_float4(0, 0, 0, 0);
-            rw.v[i] = (gn < p.N) ? ld4(p.W + (size_t)gn * p.ldw + k0 + scol) : make_float4(0, 0, 0, 0);
+            ra[i] = (gm < p.M && am >= 0) ? ld4(p.A + (size_t)am * p.lda + k0 + scol) : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * TN; ++i) {
+            const int gn = n0 + srow + i * 32;
+            rw[i] = (gn < p.N) ? ld4(p.W + (size_t)gn * p.ldw + k0 + scol) : make_float4(0, 0, 0, 0);
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int r = srow + i * 32;
-            st4(&lds[buf][0][r * LDS_LD + scol], ra.v[i]);
-            st4(&lds[buf][1][r * LDS_LD + scol], rw.v[i]);
-        }
+        for (int i = 0; i < 2 * TM; ++i) st4(&lds[buf][0][(srow + i * 32) * LDS_LD + scol], ra[i]);
+#pragma unroll
+        for (int i = 0; i < 2 * TN; ++i) st4(&lds[buf][1][(srow + i * 32) * LDS_LD + scol], rw[i]);
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -107,21 +111,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) gload((kt + 1) * BK);
-        const float* la = &lds[cur][0][(wr * 64 + fr) * LDS_LD + fh * 4];
-        const float* lw = &lds[cur][1][(wc * 64 + fr) * LDS_LD + fh * 4];
+        const float* la = &lds[cur][0][(wr * 32 * TM + fr) * LDS_LD + fh * 4];
+        const float* lw = &lds[cur][1][(wc * 32 * TN + fr) * LDS_LD + fh * 4];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 8) {
-            float4 a0 = ld4(la + kk), a1 = ld4(la + 32 * LDS_LD + kk);
-            float4 b0 = ld4(lw + kk), b1 = ld4(lw + 32 * LDS_LD + kk);
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+            float4 af[TM], bf[TN];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv0[e], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv1[e], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv0[e], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv1[e], acc[1][1], 0, 0, 0);
-            }
+            for (int i = 0; i < TM; ++i) af[i] = ld4(la + i * 32 * LDS_LD + kk);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = ld4(lw + j * 32 * LDS_LD + kk);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float a = e == 0 ? af[i].x : e == 1 ? af[i].y : e == 2 ? af[i].z : af[i].w;
+                        const float b = e == 0 ? bf[j].x : e == 1 ? bf[j].y : e == 2 ? bf[j].z : bf[j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+                    }
         }
         if (kt + 1 < nk) {
             lstore(cur ^ 1);
@@ -135,39 +143,41 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                         (!p.silu_mul || p.ld_silu % 4 == 0);
     if (!vec_ok) {      // odd widths (Wout: N = 159): element-wise stores
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    int row = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                    int col = n0 + wc * 64 + j * 32 + fr;
+                    int row = m0 + (wr * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                    int col = n0 + (wc * TN + j) * 32 + fr;
                     store_out(p, row, col, acc[i][j][e]);
                 }
         return;
     }
-    // transpose the 128x128 tile through LDS (the operand buffers are free now) so that every lane owns 4
-    // consecutive columns: bias / residual / gate loads and the output stores become 16-byte and row-contiguous
+    // transpose the tile through LDS (the operand buffers are free now) so that every lane owns 4 consecutive
+    // columns: bias / residual / gate loads and the output stores become 16-byte and row-contiguous
     constexpr int CLD = BN + 4;
-    float* ct = &lds[0][0][0];                       // 128 x 132 floats = 67.6 KB <= the 73.7 KB of operand buffers
+    static_assert(BM * CLD <= 2 * 2 * BMAX * LDS_LD, "output tile does not fit the operand buffers");
+    float* ct = &lds[0][0][0];
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int r = wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                ct[r * CLD + wc * 64 + j * 32 + fr] = acc[i][j][e];
+                const int r = (wr * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                ct[r * CLD + (wc * TN + j) * 32 + fr] = acc[i][j][e];
             }
     __syncthreads();
-    const int c4 = (tid & 31) * 4, col = n0 + c4;
+    constexpr int TPR = BN / 4;                      // threads per output row
+    const int c4 = (tid % TPR) * 4, col = n0 + c4;
     if (col >= p.N) return;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) bias4 = ld4(p.bias + col);
     const float sc[4] = {col + 0 < p.scale_cols ? p.scale : 1.f, col + 1 < p.scale_cols ? p.scale : 1.f,
                          col + 2 < p.scale_cols ? p.scale : 1.f, col + 3 < p.scale_cols ? p.scale : 1.f};
-    for (int r = tid >> 5; r < BM; r += 8) {
+    for (int r = tid / TPR; r < BM; r += 256 / TPR) {
         const int row = m0 + r;
         if (row >= p.M) break;
         float4 v = ld4(&ct[r * CLD + c4]);
@@ -213,13 +223,14 @@ int32_t amt_launch_gemm(const GemmParams& p, hipStream_t stream) {
     // Small products (one decode row, the 300 frames of one clip, a table, a few thousand rows of a narrow layer): a 128x128
     // tile costs its full MFMA time on one CU whatever part of it is real rows (27 us at K = 512; ~50 us measured), and with
     // fewer tiles than CUs nothing hides it.  With a plain epilogue they go to the skinny GEMM (16x16 output tiles, all of a
-    // workgroup's weight loads in flight at once): ~10 us up to M*N = 256k outputs, break-even near 1.3M (tools/bench_small_gemm.py).
+    // workgroup's weight loads in flight at once): ~10 us up to M*N = 256k outputs, break-even with the 64x64-tile variant below
+    // near 650k outputs (tools/bench_small_gemm.py).
     static long small_m = -1, small_mn = -1;
     if (small_m < 0) {
         const char* e = getenv("AMT_GEMM_SMALL_M");
         small_m = e ? atol(e) : 4096;
         const char* f = getenv("AMT_GEMM_SMALL_MN");
-        small_mn = f ? atol(f) : 1300000;
+        small_mn = f ? atol(f) : 650000;
     }
     if (p.M <= small_m && (long)p.M * p.N <= small_mn && p.K % 64 == 0 && p.K <= 1536 && !p.head_split && !p.rowadd && !p.silu_mul &&
         !p.sigmoid && !p.tile_group && !p.a_gather) {
@@ -228,8 +239,15 @@ int32_t amt_launch_gemm(const GemmParams& p, hipStream_t stream) {
         g.resid = p.resid; g.ldr = p.ldr; g.relu = p.relu; g.scale = p.scale; g.scale_cols = p.scale_cols; g.y = p.C; g.ldy = p.ldc;
         return amt_launch_decode_gemm(g, stream);
     }
-    const int ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3(ntiles), dim3(256), 0, stream, p);
+    // 128x128 tiles when there are enough of them to fill the 256 CUs a few times over, 64x64 tiles (a quarter of the MFMA
+    // work per workgroup, four times the workgroups) below that; grouped (mixture-of-experts) launches are planned in 128-row tiles
+    const int t128 = cdiv(p.M, 128) * cdiv(p.N, 128);
+    static int t64_below = -1;
+    if (t64_below < 0) { const char* e = getenv("AMT_GEMM_T64_BELOW"); t64_below = e ? atoi(e) : 768; }
+    if (p.tile_group || t128 >= t64_below)
+        hipLaunchKernelGGL((gemm_f32_kernel<2, 2>), dim3(t128), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<1, 1>), dim3(cdiv(p.M, 64) * cdiv(p.N, 64)), dim3(256), 0, stream, p);
     AMT_LAUNCH_CHECK();
     return 0;
 }
