@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     if (p.tile_group) {              // grouped mode: per-tile expert weights
-        const int g = p.tile_group[tm];
+        const int g = p.tile_group[m0 / 128];       // groups are planned in 128-row segments
         if (g < 0) return;
         p.W += (size_t)g * p.w_group_stride;
         if (p.bias) p.bias += (size_t)g * p.bias_group_stride;
@@ -239,12 +239,13 @@ int32_t amt_launch_gemm(const GemmParams& p, hipStream_t stream) {
         g.resid = p.resid; g.ldr = p.ldr; g.relu = p.relu; g.scale = p.scale; g.scale_cols = p.scale_cols; g.y = p.C; g.ldy = p.ldc;
         return amt_launch_decode_gemm(g, stream);
     }
-    // 128x128 tiles when there are enough of them to fill the 256 CUs a few times over, 64x64 tiles (a quarter of the MFMA
-    // work per workgroup, four times the workgroups) below that; grouped (mixture-of-experts) launches are planned in 128-row tiles
+    // 64x64 tiles (one accumulator per wave, four times the workgroups) measure faster than 128x128 on every shape of this
+    // model (K <= 1312: 103-110 vs 98-104 TFLOP/s at M = 32768, 85-100 vs 61-86 at M = 9600, 19 vs 50 us for a single tile row);
+    // the big tile only wins for long-K products with many tiles (4096^3: 109 vs 103).
     const int t128 = cdiv(p.M, 128) * cdiv(p.N, 128);
     static int t64_below = -1;
     if (t64_below < 0) { const char* e = getenv("AMT_GEMM_T64_BELOW"); t64_below = e ? atoi(e) : 768; }
-    if (p.tile_group || t128 >= t64_below)
+    if (t128 >= t64_below && p.K >= 2048)
         hipLaunchKernelGGL((gemm_f32_kernel<2, 2>), dim3(t128), dim3(256), 0, stream, p);
     else
         hipLaunchKernelGGL((gemm_f32_kernel<1, 1>), dim3(cdiv(p.M, 64) * cdiv(p.N, 64)), dim3(256), 0, stream, p);
