@@ -22,7 +22,9 @@ def rnd(rs, *shape, scale=1.0):
 
 
 @pytest.mark.parametrize("M,N,K,relu,resid", [(128, 128, 32, 0, False), (300, 159, 512, 0, False), (1000, 1536, 128, 1, True),
-                                             (15, 512, 512, 0, False), (257, 130, 1312, 0, True)])
+                                             (15, 512, 512, 0, False), (257, 130, 1312, 0, True),
+                                             (5000, 1024, 512, 1, True),        # 64x64-tile instantiation, many tiles
+                                             (4096, 3072, 2048, 0, False)])     # long K, >= 768 tiles: the 128x128 instantiation
 def test_linear(M, N, K, relu, resid):
     rs = np.random.RandomState(M + N)
     x, w, b = rnd(rs, M, K), rnd(rs, N, K, scale=K ** -0.5), rnd(rs, N)
