@@ -105,6 +105,7 @@ def main(argv=None):
         model.load_state_dict(torch.load(args.model_weights, map_location="cpu"))
     model = model.to(device).eval()
     lo, hi = vdist.shard_bounds(args.n_clips, rank, world)
+    streams = [torch.cuda.current_stream(device)]
     f = {k: torch.from_numpy(v[lo:hi]).to(device) for k, v in feats.items()}
     prim = torch.tensor([default_primer(k) for k in feats["key"][lo:hi, 0]], device=device)
     with torch.set_grad_enabled(False):
@@ -116,14 +117,30 @@ def main(argv=None):
                                         prim[:, 0:1], prim[:, 1:2], prim[:, 2:3],
                                         target_seq_length=args.target_seq_length_chord, beam=args.beam,
                                         max_conseq_N=max_conseq_N, max_conseq_chord=max_conseq_chord, sampler=args.sampler)
-        else:                                          # V2 generates one clip at a time like the reference
-            rows = []
-            for i in range(hi - lo):
+        else:
+            # V2 generates one clip at a time like the reference (its RoPE view ties a batch together); each clip's
+            # decode is a latency-bound chain of small launches, so several clips run concurrently, one HIP stream and
+            # one host thread each (the per-token library call releases the GIL)
+            def one(i):
                 sl = slice(i, i + 1)
-                rows.append(model.generate(f["semantic"][sl], f["key"][i], f["scene_offset"][sl], f["motion"][sl], f["emotion"][sl],
-                                           prim[i, 0:1], prim[i, 1:2], prim[i, 2:3], target_seq_length=args.target_seq_length_chord,
-                                           beam=args.beam, max_conseq_N=max_conseq_N, max_conseq_chord=max_conseq_chord,
-                                           sampler=args.sampler))
+                with torch.cuda.stream(streams[i % len(streams)]):
+                    out = model.generate(f["semantic"][sl], f["key"][i], f["scene_offset"][sl], f["motion"][sl], f["emotion"][sl],
+                                         prim[i, 0:1], prim[i, 1:2], prim[i, 2:3], target_seq_length=args.target_seq_length_chord,
+                                         beam=args.beam, max_conseq_N=max_conseq_N, max_conseq_chord=max_conseq_chord,
+                                         sampler=args.sampler)
+                    torch.cuda.current_stream().synchronize()
+                return out
+            n_local = hi - lo
+            rows = []
+            if n_local:
+                rows.append(one(0))                    # first clip alone: builds the derived tables and packed weights once
+                workers = max(1, min(args.v2_streams, n_local - 1))
+                streams = [torch.cuda.Stream(device=device) for _ in range(workers)]
+                torch.cuda.synchronize(device)
+                if n_local > 1:
+                    from concurrent.futures import ThreadPoolExecutor
+                    with ThreadPoolExecutor(max_workers=workers) as pool:
+                        rows += list(pool.map(one, range(1, n_local)))
             toks = torch.cat(rows) if rows else torch.empty(0, args.target_seq_length_chord, dtype=torch.long, device=device)
         toks = vdist.all_gather_sequences(toks, args.n_clips)
         reg_rows = None
