@@ -25,6 +25,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+if not os.path.exists(os.path.join(ROOT, "video2music_amd", "lib", "libamt_hip.so")) and int(os.environ.get("LOCAL_RANK", "0")) == 0:
+    import subprocess                                                        # the library is a build artefact: build it once if absent
+    subprocess.check_call([os.path.join(ROOT, "video2music_amd", "csrc", "build.sh")], stdout=sys.stderr)
 from video2music_amd import dist as vdist                                   # noqa: E402
 from video2music_amd import synthetic                                        # noqa: E402
 from video2music_amd.model.video_music_transformer import VideoMusicTransformer   # noqa: E402
