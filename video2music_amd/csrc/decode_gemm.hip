@@ -14,6 +14,8 @@
 //    fixed order through LDS (deterministic, no atomics);
 //  * the (normalised) input rows are staged once in LDS ([16][K+8] floats: conflict-free
 //    ds_read_b128 A-fragments).
+#include <mutex>
+
 #include "amt_common.h"
 #include "kernels.h"
 
@@ -276,9 +278,11 @@ int32_t amt_launch_pack_weight(const float* W, float* P, int N, int K, hipStream
 // a few zero words in global memory per device (absent bias / residual / position read these)
 static int32_t zero_words(const float** out) {
     static float* buf[64] = {nullptr};
+    static std::mutex mu;                            // several host threads may launch concurrently (one stream each)
     int dev = 0;
     AMT_HIP(hipGetDevice(&dev));
     AMT_CHECK_ARG(dev >= 0 && dev < 64, "decode_gemm: device ordinal %d out of range", dev);
+    std::lock_guard<std::mutex> lock(mu);
     if (!buf[dev]) {
         AMT_HIP(hipMalloc((void**)&buf[dev], 256));
         AMT_HIP(hipMemset(buf[dev], 0, 256));
