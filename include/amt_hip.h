@@ -220,13 +220,13 @@ int32_t amt_moe_combine_fwd(const float* y_rows, const int32_t* slot_pos, const 
  * tab: device pointers, 10 global (PR, PA, wkey, Linear_chord.bias, rope cache (max_seq, E/2, 2), decoder.norm w, b,
  * packed Wout, Wout b, an int32 pair {0, 1}) then 32 per layer (packed self in_proj, its bias, packed out_proj, b,
  * norm1 w, b, packed cross in_proj rows 0:E, its bias, packed out_proj, b, norm2 w, b, norm3 w, b, self K cache, V cache
- * (max_seq, E), cross K (roped), V (S, E), router w (null = plain GLU layer), router b, packed linear1, b, packed gate, b,
+ * (head-major: H, max_seq, hd), cross K (roped), V (head-major: H, S, hd), router w (null = plain GLU layer), router b, packed linear1, b, packed gate, b,
  * packed linear2, b (per expert, stacked, for a MoE layer), shared expert's six tensors (packed weights) or null).
  * ws: amt_v2_step_ws_floats(E, dff, n_exp) floats.  E, dff multiples of 64, at most 1536. */
 int32_t amt_pack_weight_fwd(const float* w, float* out, int32_t N, int32_t K, void* stream);
 int64_t amt_v2_step_ws_floats(int32_t E, int32_t dff, int32_t n_exp);
 int32_t amt_v2_step(const void* const* tab, int32_t n_layers, int32_t H, int32_t E, int32_t dff, int32_t n_exp,
-                    int32_t S, int32_t t, int32_t root, int32_t attr, float key, float* logits_out, float* ws, void* stream);
+                    int32_t S, int32_t max_seq, int32_t t, int32_t root, int32_t attr, float key, float* logits_out, float* ws, void* stream);
 
 /* ---- regression head VideoRegression(regModel='bimamba+') (model/video_regression.py:104-245) ---- */
 /* Depthwise causal Conv1d(kernel K, padding K-1)[..., :L] + SiLU of MambaBlock.forward (mamba.py:172-175,268-272):

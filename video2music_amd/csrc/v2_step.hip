@@ -38,6 +38,26 @@ __global__ void copy_kernel(const float* __restrict__ src, float* __restrict__ d
     if (i < n) st4(dst + i, ld4(src + i));
 }
 
+// RoPE of one position's full d_model vector (pair i rotated by the cache row's (cos, sin) i, as rope_kernel does), times
+// `scale`, placed either contiguously (query) or as row t of a head-major [H][cap][hd] cache (key); rope == null: plain copy
+// (value).  One thread per pair.
+__global__ void rope_place_kernel(const float* __restrict__ x, const float* __restrict__ rope, float* __restrict__ dst,
+                                  float scale, int E, int hd, int cap, int t, int head_major) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * i >= E) return;
+    const float x0 = x[2 * i], x1 = x[2 * i + 1];
+    float y0 = x0, y1 = x1;
+    if (rope) {
+        const float c = rope[2 * i], sn = rope[2 * i + 1];
+        y0 = x0 * c - x1 * sn;
+        y1 = x1 * c + x0 * sn;
+    }
+    const int e = 2 * i, h = e / hd, cc = e - h * hd;
+    float* o = head_major ? dst + ((size_t)h * cap + t) * hd + cc : dst + e;
+    o[0] = y0 * scale;
+    o[1] = y1 * scale;
+}
+
 // h = u * silu(g)   (GLUExpert.forward, moe.py:44-49)
 __global__ void glu_mul_kernel(const float* __restrict__ u, const float* __restrict__ g, float* __restrict__ h, int n) {
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -50,14 +70,17 @@ __global__ void glu_mul_kernel(const float* __restrict__ u, const float* __restr
     }
 }
 
-int32_t attn_one(const float* q, const float* k, const float* v, float* o, int E, int H, int hd, int Lk, hipStream_t s) {
-    AttnParams a{};
-    a.q = q; a.k = k; a.v = v; a.o = o;
-    a.q_bs = a.k_bs = a.v_bs = a.o_bs = (size_t)E;
-    a.q_hs = a.k_hs = a.v_hs = a.o_hs = (size_t)hd;
-    a.q_ls = a.k_ls = a.v_ls = a.o_ls = (size_t)E;
-    a.B = 1; a.H = H; a.Lq = 1; a.Lk = Lk; a.hd = hd; a.causal = 0; a.kv_group = 1; a.q_scale = 1.0f / sqrtf((float)hd);
-    return amt_launch_attn_prefill(a, s);
+// one query over a head-major cache [H][cap][hd] on the K/V-streaming decode kernel (q already scaled)
+int32_t attn_one(const float* q, const float* k, const float* v, float* o, int H, int hd, int cap, int n_keys, hipStream_t s) {
+    AttnDecodeParams a{};
+    a.q = q; a.k = k; a.v = v; a.o = o; a.B = 1; a.H = H; a.hd = hd; a.cap = cap; a.n_keys = n_keys;
+    return amt_launch_attn_decode(a, s);
+}
+
+int32_t place(const float* x, const float* rope, float* dst, float scale, int E, int hd, int cap, int t, int head_major, hipStream_t s) {
+    hipLaunchKernelGGL(rope_place_kernel, dim3(cdiv(E / 2, 256)), dim3(256), 0, s, x, rope, dst, scale, E, hd, cap, t, head_major);
+    AMT_LAUNCH_CHECK();
+    return 0;
 }
 
 // one row through a pre-packed weight on the skinny GEMM: y[N] = x[K] . W^T + b (+ resid); optional device-chosen group
@@ -95,13 +118,14 @@ extern "C" int32_t amt_pack_weight_fwd(const float* w, float* out, int32_t N, in
 }
 
 extern "C" int32_t amt_v2_step(const void* const* tab, int32_t n_layers, int32_t H, int32_t E, int32_t dff, int32_t n_exp,
-                               int32_t S, int32_t t, int32_t root, int32_t attr, float key, float* logits_out, float* ws,
+                               int32_t S, int32_t max_seq, int32_t t, int32_t root, int32_t attr, float key, float* logits_out, float* ws,
                                void* stream) {
     AMT_CHECK_ARG(tab && logits_out && ws, "amt_v2_step: null pointer");
-    AMT_CHECK_ARG(n_layers > 0 && H > 0 && E % H == 0 && E % 64 == 0 && dff % 64 == 0 && E <= 1536 && dff <= 1536 && t >= 0 && S > 0,
+    AMT_CHECK_ARG(n_layers > 0 && H > 0 && E % H == 0 && E % 64 == 0 && dff % 64 == 0 && E <= 1536 && dff <= 1536 && t >= 0 && t < max_seq && S > 0,
                   "amt_v2_step: bad shape (E and dff must be multiples of 64, at most 1536)");
     hipStream_t s = (hipStream_t)stream;
     const int hd = E / H;
+    const float qscale = 1.0f / sqrtf((float)hd);
     auto G = [&](int i) { return (const float*)tab[i]; };
     float* x = ws; float* y = x + E; float* qkv = y + E; float* q = qkv + 3 * E; float* o = q + E; float* u = o + E;
     float* Y2 = u + E;                                    // two expert outputs [2][E]
@@ -117,19 +141,18 @@ extern "C" int32_t amt_v2_step(const void* const* tab, int32_t n_layers, int32_t
         const void* const* L = tab + G_PTRS + (size_t)l * L_PTRS;
         auto P = [&](int i) { return (const float*)L[i]; };
         float* kc = (float*)L[L_KC]; float* vc = (float*)L[L_VC];
-        // self-attention
+        // self-attention: caches are head-major [H][max_seq][hd]; q is scaled here (the decode kernel takes a scaled query)
         if ((rc = lin(x, P(L_SAW), P(L_SAB), nullptr, qkv, 3 * E, E, s))) return rc;
-        if ((rc = amt_launch_rope(qkv, rope_row, q, 1, 1, 1, E, E / 2, s))) return rc;
-        if ((rc = amt_launch_rope(qkv + E, rope_row, kc + (size_t)t * E, 1, 1, 1, E, E / 2, s))) return rc;
-        hipLaunchKernelGGL(copy_kernel, dim3(cdiv(E, 1024)), dim3(256), 0, s, qkv + 2 * E, vc + (size_t)t * E, E);
-        AMT_LAUNCH_CHECK();
-        if ((rc = attn_one(q, kc, vc, o, E, H, hd, t + 1, s))) return rc;
+        if ((rc = place(qkv, rope_row, q, qscale, E, hd, 0, 0, 0, s))) return rc;
+        if ((rc = place(qkv + E, rope_row, kc, 1.f, E, hd, max_seq, t, 1, s))) return rc;
+        if ((rc = place(qkv + 2 * E, nullptr, vc, 1.f, E, hd, max_seq, t, 1, s))) return rc;
+        if ((rc = attn_one(q, kc, vc, o, H, hd, max_seq, t + 1, s))) return rc;
         if ((rc = lin(o, P(L_SAOW), P(L_SAOB), x, u, E, E, s))) return rc;
         if ((rc = amt_launch_layernorm(u, nullptr, P(L_N1W), P(L_N1B), nullptr, nullptr, x, 1, E, 1e-5f, s))) return rc;
-        // cross-attention over the clip's (roped) video keys
+        // cross-attention over the clip's (roped) video keys, head-major [H][S][hd]
         if ((rc = lin(x, P(L_CAW), P(L_CAB), nullptr, qkv, E, E, s))) return rc;
-        if ((rc = amt_launch_rope(qkv, rope_row, q, 1, 1, 1, E, E / 2, s))) return rc;
-        if ((rc = attn_one(q, P(L_KX), P(L_VX), o, E, H, hd, S, s))) return rc;
+        if ((rc = place(qkv, rope_row, q, qscale, E, hd, 0, 0, 0, s))) return rc;
+        if ((rc = attn_one(q, P(L_KX), P(L_VX), o, H, hd, S, S, s))) return rc;
         if ((rc = lin(o, P(L_CAOW), P(L_CAOB), x, u, E, E, s))) return rc;
         if ((rc = amt_launch_layernorm(u, nullptr, P(L_N2W), P(L_N2B), nullptr, nullptr, x, 1, E, 1e-5f, s))) return rc;
         // feed-forward: GLU expert (shallow layers) or shared mixture of experts (router, the two chosen experts read

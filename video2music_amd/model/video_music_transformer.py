@@ -607,7 +607,12 @@ class VideoMusicTransformer_V2(nn.Module):
             add(t)
         from .moe import GLUExpert, _stack
         dff = None
-        for lyr, (kc, vc), (kx, vx) in zip(self.transformer.decoder.layers, st["self"], st["cross"]):
+        # the one-call step streams K/V with the decode-attention kernel: head-major caches (H, rows, hd)
+        st["self_hm"] = [(torch.empty(H, self.max_seq_video, hd, device=dev), torch.empty(H, self.max_seq_video, hd, device=dev))
+                         for _ in st["self"]]
+        st["cross_hm"] = [(k.view(S, H, hd).permute(1, 0, 2).contiguous(), v.view(S, H, hd).permute(1, 0, 2).contiguous())
+                          for k, v in st["cross"]]
+        for lyr, (kc, vc), (kx, vx) in zip(self.transformer.decoder.layers, st["self_hm"], st["cross_hm"]):
             sa, ca = lyr.self_attn, lyr.cross_attn
             for t in (packed(sa.in_proj_weight), sa.in_proj_bias, packed(sa.out_proj.weight), sa.out_proj.bias, lyr.norm1.weight, lyr.norm1.bias,
                       packed(ca.in_proj_weight, rows=E), ca.in_proj_bias, packed(ca.out_proj.weight), ca.out_proj.bias, lyr.norm2.weight,
@@ -645,7 +650,8 @@ class VideoMusicTransformer_V2(nn.Module):
 
     def _decode_step_native(self, root, attr, key, t, st):
         """`_decode_step` issued by one library call (amt_v2_step): logits (159,) for input position t."""
-        _lib.call("amt_v2_step", st["tab"], self.nlayers, self.nhead, self.d_model, st["dff"], self.n_experts, st["S"], int(t),
+        _lib.call("amt_v2_step", st["tab"], self.nlayers, self.nhead, self.d_model, st["dff"], self.n_experts, st["S"],
+                  self.max_seq_video, int(t),
                   int(root), int(attr), float(key), _lib.ptr(st["logits"]), _lib.ptr(st["ws"]), _lib.stream_ptr())
         return st["logits"]
 
