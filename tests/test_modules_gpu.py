@@ -139,3 +139,29 @@ def test_generate_cli_reads_feature_files_and_writes_lab(tmp_path):
     ref = m.generate_batch(t("semantic"), key.cuda(), t("scene_offset"), t("motion"), t("emotion"), prim[:, 0:1], prim[:, 1:2], prim[:, 2:3],
                            target_seq_length=24, beam=0, sampler="argmax")
     assert torch.equal(ref.cpu(), toks)
+
+
+def test_bench_line_contract(tmp_path):
+    """bench.py prints ONE JSON line with the driver's keys, the roofline object and the cpu_baseline object (small config)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--seq", "48", "--batch", "3",
+                          "--layers", "2", "--d_model", "128"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "chord_tokens_per_sec_generated" and d["n_gpus"] == 1 and d["steps"] == 1 and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["higher_is_better"] is True and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert "traffic" in r and r["avg_launch_us"] > 0 and r["whole_step"]["algorithmic_bytes_per_step"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert abs(d["value"] - 3 * 47 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-2
