@@ -222,11 +222,14 @@ int32_t amt_moe_combine_fwd(const float* y_rows, const int32_t* slot_pos, const 
  * norm1 w, b, packed cross in_proj rows 0:E, its bias, packed out_proj, b, norm2 w, b, norm3 w, b, self K cache, V cache
  * (head-major: H, max_seq, hd), cross K (roped), V (head-major: H, S, hd), router w (null = plain GLU layer), router b, packed linear1, b, packed gate, b,
  * packed linear2, b (per expert, stacked, for a MoE layer), shared expert's six tensors (packed weights) or null).
- * ws: amt_v2_step_ws_floats(E, dff, n_exp) floats.  E, dff multiples of 64, at most 1536. */
+ * ws: amt_v2_step_ws_floats(E, dff, n_exp) floats.  E, dff multiples of 64, at most 1536.
+ * state_dev (optional): int32 {position, root, attr} in device memory; when given, t / root / attr are read there and the
+ * position is incremented at the end of the step, so that one captured graph of the step can be replayed for every token. */
 int32_t amt_pack_weight_fwd(const float* w, float* out, int32_t N, int32_t K, void* stream);
 int64_t amt_v2_step_ws_floats(int32_t E, int32_t dff, int32_t n_exp);
 int32_t amt_v2_step(const void* const* tab, int32_t n_layers, int32_t H, int32_t E, int32_t dff, int32_t n_exp,
-                    int32_t S, int32_t max_seq, int32_t t, int32_t root, int32_t attr, float key, float* logits_out, float* ws, void* stream);
+                    int32_t S, int32_t max_seq, int32_t t, int32_t root, int32_t attr, float key, const int32_t* state_dev,
+                    float* logits_out, float* ws, void* stream);
 
 /* ---- regression head VideoRegression(regModel='bimamba+') (model/video_regression.py:104-245) ---- */
 /* Depthwise causal Conv1d(kernel K, padding K-1)[..., :L] + SiLU of MambaBlock.forward (mamba.py:172-175,268-272):

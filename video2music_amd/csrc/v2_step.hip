@@ -21,8 +21,11 @@ enum { G_PR, G_PA, G_WKEY, G_CBIAS, G_ROPE, G_FNW, G_FNB, G_WOUT, G_BOUT, G_SLOT
 enum { L_SAW, L_SAB, L_SAOW, L_SAOB, L_N1W, L_N1B, L_CAW, L_CAB, L_CAOW, L_CAOB, L_N2W, L_N2B, L_N3W, L_N3B,
        L_KC, L_VC, L_KX, L_VX, L_GATEW, L_GATEB, L_W1, L_B1, L_WG, L_BG, L_W2, L_B2, L_SW1, L_SB1, L_SWG, L_SBG, L_SW2, L_SB2 };
 
-__global__ void embed_one_kernel(int root, int attr, float kv, const float* __restrict__ PR, const float* __restrict__ PA,
-                                 const float* __restrict__ wkey, const float* __restrict__ bias, float* __restrict__ out, int d) {
+// (root, attr) either as launch arguments or, for a captured step graph, from device memory (tok[0], tok[1])
+__global__ void embed_one_kernel(int root, int attr, const int* __restrict__ tok, float kv, const float* __restrict__ PR,
+                                 const float* __restrict__ PA, const float* __restrict__ wkey, const float* __restrict__ bias,
+                                 float* __restrict__ out, int d) {
+    if (tok) { root = tok[0]; attr = tok[1]; }
     for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
         const float4 pr = ld4(PR + (size_t)root * d + c), pa = ld4(PA + (size_t)attr * d + c);
         const float4 wk = ld4(wkey + c), bb = ld4(bias + c);
@@ -33,18 +36,16 @@ __global__ void embed_one_kernel(int root, int attr, float kv, const float* __re
     }
 }
 
-__global__ void copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int n) {
-    const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i < n) st4(dst + i, ld4(src + i));
-}
+__global__ void advance_kernel(int* pos) { *pos += 1; }
 
 // RoPE of one position's full d_model vector (pair i rotated by the cache row's (cos, sin) i, as rope_kernel does), times
 // `scale`, placed either contiguously (query) or as row t of a head-major [H][cap][hd] cache (key); rope == null: plain copy
 // (value).  One thread per pair.
 __global__ void rope_place_kernel(const float* __restrict__ x, const float* __restrict__ rope, float* __restrict__ dst,
-                                  float scale, int E, int hd, int cap, int t, int head_major) {
+                                  float scale, int E, int hd, int cap, int t, const int* __restrict__ pos, int head_major) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (2 * i >= E) return;
+    if (pos) { t = *pos; if (rope) rope += (size_t)t * E; }      // captured step: position from device memory, rope = table base
     const float x0 = x[2 * i], x1 = x[2 * i + 1];
     float y0 = x0, y1 = x1;
     if (rope) {
@@ -71,14 +72,16 @@ __global__ void glu_mul_kernel(const float* __restrict__ u, const float* __restr
 }
 
 // one query over a head-major cache [H][cap][hd] on the K/V-streaming decode kernel (q already scaled)
-int32_t attn_one(const float* q, const float* k, const float* v, float* o, int H, int hd, int cap, int n_keys, hipStream_t s) {
+int32_t attn_one(const float* q, const float* k, const float* v, float* o, int H, int hd, int cap, int n_keys, const int* pos,
+                 hipStream_t s) {
     AttnDecodeParams a{};
-    a.q = q; a.k = k; a.v = v; a.o = o; a.B = 1; a.H = H; a.hd = hd; a.cap = cap; a.n_keys = n_keys;
+    a.q = q; a.k = k; a.v = v; a.o = o; a.B = 1; a.H = H; a.hd = hd; a.cap = cap; a.n_keys = n_keys; a.pos = pos;   // pos: keys 0..*pos
     return amt_launch_attn_decode(a, s);
 }
 
-int32_t place(const float* x, const float* rope, float* dst, float scale, int E, int hd, int cap, int t, int head_major, hipStream_t s) {
-    hipLaunchKernelGGL(rope_place_kernel, dim3(cdiv(E / 2, 256)), dim3(256), 0, s, x, rope, dst, scale, E, hd, cap, t, head_major);
+int32_t place(const float* x, const float* rope, float* dst, float scale, int E, int hd, int cap, int t, const int* pos,
+              int head_major, hipStream_t s) {
+    hipLaunchKernelGGL(rope_place_kernel, dim3(cdiv(E / 2, 256)), dim3(256), 0, s, x, rope, dst, scale, E, hd, cap, t, pos, head_major);
     AMT_LAUNCH_CHECK();
     return 0;
 }
@@ -118,8 +121,8 @@ extern "C" int32_t amt_pack_weight_fwd(const float* w, float* out, int32_t N, in
 }
 
 extern "C" int32_t amt_v2_step(const void* const* tab, int32_t n_layers, int32_t H, int32_t E, int32_t dff, int32_t n_exp,
-                               int32_t S, int32_t max_seq, int32_t t, int32_t root, int32_t attr, float key, float* logits_out, float* ws,
-                               void* stream) {
+                               int32_t S, int32_t max_seq, int32_t t, int32_t root, int32_t attr, float key, const int32_t* state_dev,
+                               float* logits_out, float* ws, void* stream) {
     AMT_CHECK_ARG(tab && logits_out && ws, "amt_v2_step: null pointer");
     AMT_CHECK_ARG(n_layers > 0 && H > 0 && E % H == 0 && E % 64 == 0 && dff % 64 == 0 && E <= 1536 && dff <= 1536 && t >= 0 && t < max_seq && S > 0,
                   "amt_v2_step: bad shape (E and dff must be multiples of 64, at most 1536)");
@@ -134,25 +137,29 @@ extern "C" int32_t amt_v2_step(const void* const* tab, int32_t n_layers, int32_t
     float* moe_w = ffs + 3 * dff;                         // routing weights [2], then indices [2]
     int32_t* moe_idx = (int32_t*)(moe_w + 4);
     int32_t rc;
-    hipLaunchKernelGGL(embed_one_kernel, dim3(1), dim3(128), 0, s, root, attr, key, G(G_PR), G(G_PA), G(G_WKEY), G(G_CBIAS), x, E);
+    // state_dev (optional, for a captured step graph): {position, root, attr} in device memory; the step then reads them there
+    // and increments the position at its end, so one captured graph serves every token
+    const int* pos = (const int*)state_dev;
+    const int* tok = pos ? pos + 1 : nullptr;
+    hipLaunchKernelGGL(embed_one_kernel, dim3(1), dim3(128), 0, s, root, attr, tok, key, G(G_PR), G(G_PA), G(G_WKEY), G(G_CBIAS), x, E);
     AMT_LAUNCH_CHECK();
-    const float* rope_row = G(G_ROPE) + (size_t)t * E;    // cache row t: E/2 (cos, sin) pairs
+    const float* rope_row = pos ? G(G_ROPE) : G(G_ROPE) + (size_t)t * E;    // cache row t: E/2 (cos, sin) pairs
     for (int l = 0; l < n_layers; ++l) {
         const void* const* L = tab + G_PTRS + (size_t)l * L_PTRS;
         auto P = [&](int i) { return (const float*)L[i]; };
         float* kc = (float*)L[L_KC]; float* vc = (float*)L[L_VC];
         // self-attention: caches are head-major [H][max_seq][hd]; q is scaled here (the decode kernel takes a scaled query)
         if ((rc = lin(x, P(L_SAW), P(L_SAB), nullptr, qkv, 3 * E, E, s))) return rc;
-        if ((rc = place(qkv, rope_row, q, qscale, E, hd, 0, 0, 0, s))) return rc;
-        if ((rc = place(qkv + E, rope_row, kc, 1.f, E, hd, max_seq, t, 1, s))) return rc;
-        if ((rc = place(qkv + 2 * E, nullptr, vc, 1.f, E, hd, max_seq, t, 1, s))) return rc;
-        if ((rc = attn_one(q, kc, vc, o, H, hd, max_seq, t + 1, s))) return rc;
+        if ((rc = place(qkv, rope_row, q, qscale, E, hd, 0, 0, pos, 0, s))) return rc;
+        if ((rc = place(qkv + E, rope_row, kc, 1.f, E, hd, max_seq, t, pos, 1, s))) return rc;
+        if ((rc = place(qkv + 2 * E, nullptr, vc, 1.f, E, hd, max_seq, t, pos, 1, s))) return rc;
+        if ((rc = attn_one(q, kc, vc, o, H, hd, max_seq, t + 1, pos, s))) return rc;
         if ((rc = lin(o, P(L_SAOW), P(L_SAOB), x, u, E, E, s))) return rc;
         if ((rc = amt_launch_layernorm(u, nullptr, P(L_N1W), P(L_N1B), nullptr, nullptr, x, 1, E, 1e-5f, s))) return rc;
         // cross-attention over the clip's (roped) video keys, head-major [H][S][hd]
         if ((rc = lin(x, P(L_CAW), P(L_CAB), nullptr, qkv, E, E, s))) return rc;
-        if ((rc = place(qkv, rope_row, q, qscale, E, hd, 0, 0, 0, s))) return rc;
-        if ((rc = attn_one(q, P(L_KX), P(L_VX), o, H, hd, S, S, s))) return rc;
+        if ((rc = place(qkv, rope_row, q, qscale, E, hd, 0, 0, pos, 0, s))) return rc;
+        if ((rc = attn_one(q, P(L_KX), P(L_VX), o, H, hd, S, S, nullptr, s))) return rc;
         if ((rc = lin(o, P(L_CAOW), P(L_CAOB), x, u, E, E, s))) return rc;
         if ((rc = amt_launch_layernorm(u, nullptr, P(L_N2W), P(L_N2B), nullptr, nullptr, x, 1, E, 1e-5f, s))) return rc;
         // feed-forward: GLU expert (shallow layers) or shared mixture of experts (router, the two chosen experts read
@@ -174,5 +181,7 @@ extern "C" int32_t amt_v2_step(const void* const* tab, int32_t n_layers, int32_t
         float* tmp = x; x = u; u = tmp;
     }
     if ((rc = amt_launch_layernorm(x, nullptr, G(G_FNW), G(G_FNB), nullptr, nullptr, y, 1, E, 1e-5f, s))) return rc;
-    return lin(y, G(G_WOUT), G(G_BOUT), nullptr, logits_out, 159, E, s);
+    if ((rc = lin(y, G(G_WOUT), G(G_BOUT), nullptr, logits_out, 159, E, s))) return rc;
+    if (pos) { hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, s, (int*)state_dev); AMT_LAUNCH_CHECK(); }
+    return 0;
 }

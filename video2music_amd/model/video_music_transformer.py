@@ -19,6 +19,7 @@ Differences a caller can observe, all additive:
 """
 import ctypes as C
 import math
+import threading
 
 import torch
 import torch.nn as nn
@@ -27,6 +28,7 @@ from .. import _lib
 from ..utilities.constants import (CHORD_ATTR_PAD, CHORD_ATTR_SIZE, CHORD_END, CHORD_PAD, CHORD_ROOT_PAD,
                                    CHORD_ROOT_SIZE, CHORD_SIZE, IS_SEPERATED, SCENE_OFFSET_MAX)
 
+_CAPTURE_LOCK = threading.Lock()
 MAX_DECODE_BATCH = 32          # clips per library call; larger batches are processed in slices
 
 
@@ -648,12 +650,27 @@ class VideoMusicTransformer_V2(nn.Module):
         st["logits"] = torch.empty(CHORD_SIZE, device=dev, dtype=torch.float32)
         return st
 
-    def _decode_step_native(self, root, attr, key, t, st):
-        """`_decode_step` issued by one library call (amt_v2_step): logits (159,) for input position t."""
+    def _decode_step_native(self, root, attr, key, t, st, state=None):
+        """`_decode_step` issued by one library call (amt_v2_step): logits (159,) for input position t.  With `state`
+        (int32 device tensor {position, root, attr}) the step reads those from device memory and increments the position."""
         _lib.call("amt_v2_step", st["tab"], self.nlayers, self.nhead, self.d_model, st["dff"], self.n_experts, st["S"],
-                  self.max_seq_video, int(t),
-                  int(root), int(attr), float(key), _lib.ptr(st["logits"]), _lib.ptr(st["ws"]), _lib.stream_ptr())
+                  self.max_seq_video, int(t), int(root), int(attr), float(key), _lib.ptr(state), _lib.ptr(st["logits"]),
+                  _lib.ptr(st["ws"]), _lib.stream_ptr())
         return st["logits"]
+
+    def _step_graph(self, key, st, root0, attr0):
+        """Runs position 0 eagerly through the device-state form of the step, then captures that step once: every later
+        token is `state[1:] = (root, attr)` + one graph replay (≈130 launches at replay cost instead of launch cost)."""
+        dev = st["ws"].device
+        state = torch.tensor([0, int(root0), int(attr0)], dtype=torch.int32, device=dev)
+        self._decode_step_native(0, 0, key, 0, st, state)             # position 0 (also the warm-up the capture needs)
+        torch.cuda.current_stream().synchronize()
+        g = torch.cuda.CUDAGraph()
+        # several clips may be decoded by concurrent host threads (one stream each): captures are serialised, and
+        # thread-local capture mode keeps the other threads' launches from invalidating this one
+        with _CAPTURE_LOCK, torch.cuda.graph(g, capture_error_mode="thread_local"):
+            self._decode_step_native(0, 0, key, 0, st, state)
+        return g, state
 
     def _decode_step(self, root_t, attr_t, key, t, st):
         """Logits (159,) for input position t given the cached positions < t (appends position t to the caches)."""
@@ -718,11 +735,16 @@ class VideoMusicTransformer_V2(nn.Module):
         if use_cache:
             key_val = float(feature_key.reshape(-1)[0])
             st = self._cache_init(memory, S)
-            for t in range(P - 1):          # primer positions whose logits are not needed: fill the caches
-                self._decode_step_native(gen_root[0, t], gen_attr[0, t], key_val, t, st)
+            graph, state = self._step_graph(key_val, st, gen_root[0, 0], gen_attr[0, 0])      # position 0 done
+            for t in range(1, P - 1):       # primer positions whose logits are not needed: fill the caches
+                state[1:] = torch.stack((gen_root[0, t], gen_attr[0, t])).to(torch.int32)
+                graph.replay()
         while cur < T:
             if use_cache:
-                row = self._decode_step_native(gen_root[0, cur - 1], gen_attr[0, cur - 1], key_val, cur - 1, st).cpu()
+                if cur - 1 > 0:             # (position 0 already ran inside _step_graph; its logits are in st["logits"])
+                    state[1:] = torch.stack((gen_root[0, cur - 1], gen_attr[0, cur - 1])).to(torch.int32)
+                    graph.replay()
+                row = st["logits"].cpu()
             else:
                 row = self._decode(gen_root[:, :cur], gen_attr[:, :cur], feature_key, memory, B, S)[0, cur - 1].cpu()
             probs = torch.softmax(row / temperature, dim=-1)[:CHORD_END]
