@@ -121,23 +121,25 @@ def main(argv=None):
             # V2 generates one clip at a time like the reference (its RoPE view ties a batch together); each clip's
             # decode is a latency-bound chain of small launches, so several clips run concurrently, one HIP stream and
             # one host thread each (the per-token library call releases the GIL)
-            def one(i):
+            def one(i, use_graph=False):
                 sl = slice(i, i + 1)
                 with torch.cuda.stream(streams[i % len(streams)]):
                     out = model.generate(f["semantic"][sl], f["key"][i], f["scene_offset"][sl], f["motion"][sl], f["emotion"][sl],
                                          prim[i, 0:1], prim[i, 1:2], prim[i, 2:3], target_seq_length=args.target_seq_length_chord,
                                          beam=args.beam, max_conseq_N=max_conseq_N, max_conseq_chord=max_conseq_chord,
-                                         sampler=args.sampler)
+                                         sampler=args.sampler, use_graph=use_graph)
                     torch.cuda.current_stream().synchronize()
                 return out
             n_local = hi - lo
             rows = []
             if n_local:
-                rows.append(one(0))                    # first clip alone: builds the derived tables and packed weights once
+                rows.append(one(0, True))              # first clip alone: builds the derived tables and packed weights once
                 workers = max(1, min(args.v2_streams, n_local - 1))
                 streams = [torch.cuda.Stream(device=device) for _ in range(workers)]
                 torch.cuda.synchronize(device)
-                if n_local > 1:
+                if n_local > 1 and workers == 1:        # one at a time: each clip replays a captured step graph
+                    rows += [one(i, True) for i in range(1, n_local)]
+                elif n_local > 1:                      # concurrent clips issue their steps eagerly (no capture across threads)
                     from concurrent.futures import ThreadPoolExecutor
                     with ThreadPoolExecutor(max_workers=workers) as pool:
                         rows += list(pool.map(one, range(1, n_local)))

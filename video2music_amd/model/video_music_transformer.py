@@ -708,11 +708,14 @@ class VideoMusicTransformer_V2(nn.Module):
 
     def generate(self, feature_semantic_list=[], feature_key=None, feature_scene_offset=None, feature_motion=None,
                  feature_emotion=None, primer=None, primer_root=None, primer_attr=None, target_seq_length=300, beam=0,
-                 beam_chance=1.0, max_conseq_N=0, max_conseq_chord=2, temperature=1.0, sampler="categorical", use_cache=True):
+                 beam_chance=1.0, max_conseq_N=0, max_conseq_chord=2, temperature=1.0, sampler="categorical", use_cache=True,
+                 use_graph=True):
         """Reference loop (:518-609) for one clip; the decision runs on the host like the reference's python loop
         (softmax[:157] / temperature, N and repeat suppression, Categorical sample or arg-max).  The reference
         re-runs the whole model every step; here the encoder runs once and the decoder one token at a time over
-        cached K/V (`use_cache=False` keeps the per-step re-forward of the decoder stack)."""
+        cached K/V (`use_cache=False` keeps the per-step re-forward of the decoder stack; `use_graph=False` issues the cached
+        step eagerly instead of replaying a captured graph — required when several host threads generate concurrently,
+        stream capture does not tolerate the other threads' synchronisations)."""
         from ..utilities.constants import chord_to_root_attr
         assert (not self.training), "Cannot generate while in training mode"
         if beam not in (0, 1):
@@ -735,15 +738,23 @@ class VideoMusicTransformer_V2(nn.Module):
         if use_cache:
             key_val = float(feature_key.reshape(-1)[0])
             st = self._cache_init(memory, S)
-            graph, state = self._step_graph(key_val, st, gen_root[0, 0], gen_attr[0, 0])      # position 0 done
+            if use_graph:
+                graph, state = self._step_graph(key_val, st, gen_root[0, 0], gen_attr[0, 0])      # position 0 done
+            else:
+                self._decode_step_native(gen_root[0, 0], gen_attr[0, 0], key_val, 0, st)
+
+            def step(t):
+                if use_graph:
+                    state[1:] = torch.stack((gen_root[0, t], gen_attr[0, t])).to(torch.int32)
+                    graph.replay()
+                else:
+                    self._decode_step_native(gen_root[0, t], gen_attr[0, t], key_val, t, st)
             for t in range(1, P - 1):       # primer positions whose logits are not needed: fill the caches
-                state[1:] = torch.stack((gen_root[0, t], gen_attr[0, t])).to(torch.int32)
-                graph.replay()
+                step(t)
         while cur < T:
             if use_cache:
-                if cur - 1 > 0:             # (position 0 already ran inside _step_graph; its logits are in st["logits"])
-                    state[1:] = torch.stack((gen_root[0, cur - 1], gen_attr[0, cur - 1])).to(torch.int32)
-                    graph.replay()
+                if cur - 1 > 0:             # (position 0 already ran; its logits are in st["logits"])
+                    step(cur - 1)
                 row = st["logits"].cpu()
             else:
                 row = self._decode(gen_root[:, :cur], gen_attr[:, :cur], feature_key, memory, B, S)[0, cur - 1].cpu()
