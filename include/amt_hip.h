@@ -83,6 +83,12 @@ int32_t amt_prefill(amt_handle* h, int32_t B, int32_t L, const int64_t* root_ids
 int32_t amt_generate_begin(amt_handle* h, int32_t B, const int64_t* primer, const int64_t* primer_root,
                            const int64_t* primer_attr, int32_t P, int32_t primer_per_clip, const float* key,
                            int32_t T, int32_t beam, int32_t max_conseq_N, int32_t max_conseq_chord, void* stream);
+/* Switches the sampling branch (beam=0) of the generation in progress from the arg-max decision to the
+ * reference's Categorical draw (video_music_transformer.py:1104-1105), done on device by inverse CDF:
+ * uniforms is (T,B) fp32 in [0,1), device memory, copied; the token decided from input position t of clip b
+ * is the first id whose cumulative masked probability reaches uniforms[t*B+b] * sum.  null switches back.
+ * amt_generate_begin resets to arg-max. */
+int32_t amt_generate_set_uniforms(amt_handle* h, const float* uniforms, void* stream);
 /* Runs `n_steps` decode steps with the arg-max sampler on device (hipGraph replay; oracle G2 for
  * beam=0, G1 for beam=1).  logits_out (optional) is (T,B,159): row t = logits computed from input
  * position t.  n_steps < 0 runs to the end (T-1 steps in total). */

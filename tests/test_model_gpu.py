@@ -342,3 +342,70 @@ def test_scalar_motion_feature_width():
     with torch.no_grad():
         got = m(root, root.cuda(), attr.cuda(), f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"])
     assert (got.cpu() - ref).abs().max().item() < LOGIT_TOL
+
+
+def _check_draws(toks, logits, u, P, max_conseq_N, max_conseq_chord):
+    """Every generated id is the inverse-CDF draw of the reference's decision distribution (:1085-1105) at its uniform:
+    recomputed in fp64 from the returned logits, with a band for fp32 rounding of the device's cumulative sums."""
+    toks, logits, u = toks.cpu().numpy(), logits.cpu().double(), u.cpu().double().numpy()
+    B, T = toks.shape
+    for b in range(B):
+        for cur in range(P, T):
+            pr = torch.softmax(logits[cur - 1, b], -1)[:C.CHORD_END].numpy().copy()
+            if max_conseq_N == 0:
+                pr[0] = 0.0
+            if cur >= max_conseq_chord and all(toks[b, cur - 1] == toks[b, cur - 1 - k] for k in range(1, max_conseq_chord)):
+                pr[toks[b, cur - 1]] = 0.0
+            cdf = np.cumsum(pr)
+            tok, target = int(toks[b, cur]), u[cur - 1, b] * cdf[-1]
+            assert pr[tok] > 0.0, (b, cur, tok)
+            assert (cdf[tok] - pr[tok]) - 1e-5 <= target <= cdf[tok] + 1e-5, (b, cur, tok, target, cdf[tok] - pr[tok], cdf[tok])
+
+
+@pytest.mark.parametrize("cfg,B,T,mcn,mcc", [(CFG1, 3, 48, 0, 2), (CFG1, 2, 40, 1, 3), (CFG2, 5, 96, 0, 2)])
+def test_device_categorical_draw(cfg, B, T, mcn, mcc):
+    """sampler="categorical": the draw done inside the step graph equals the inverse CDF of the decision distribution at
+    the supplied uniforms; the same uniforms give the same ids; a batch row equals the clip alone."""
+    m, _ = build(cfg, seed=2)
+    f = cu(feats_t(synthetic.synthetic_features(B, seed=99)))
+    pr, prr, pra = (torch.tensor(v) for v in zip(*[C.primer_from_name(n) for n in ("C", "G", "A:min")]))
+    P = 3
+    gen = torch.Generator().manual_seed(5)
+    u = torch.rand(T, B, generator=gen)
+    kw = dict(target_seq_length=T, beam=0, sampler="categorical", max_conseq_N=mcn, max_conseq_chord=mcc)
+    args = (f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], pr, prr, pra)
+    toks, logits = m.generate_batch(*args, uniforms=u, return_logits=True, **kw)
+    assert torch.equal(toks[:, :P].cpu(), pr.expand(B, P))
+    _check_draws(toks, logits, u, P, mcn, mcc)
+    assert torch.equal(m.generate_batch(*args, uniforms=u, **kw), toks)
+    one = m.generate_batch(*(a[1:2] for a in args[:5]), pr, prr, pra, uniforms=u[:, 1:2], **kw)
+    assert torch.equal(one[0], toks[1])
+    # the arg-max decision is back after the next begin (the switch is per generation)
+    g2 = m.generate_batch(*args, target_seq_length=T, beam=0, sampler="argmax", max_conseq_N=mcn, max_conseq_chord=mcc)
+    g2b = m.generate_batch(*args, target_seq_length=T, beam=0, sampler="argmax", max_conseq_N=mcn, max_conseq_chord=mcc)
+    assert torch.equal(g2, g2b)
+
+
+def test_device_categorical_draw_extremes_and_seed():
+    """u = 0 picks the first id with positive mass, u -> 1 one at the top of the CDF; torch.manual_seed repeats a default run; the
+    host-side multinomial sampler stays available and respects the suppression rules."""
+    m, _ = build(CFG1, seed=2)
+    B, T = 2, 24
+    f = cu(feats_t(synthetic.synthetic_features(B, seed=7)))
+    pr, prr, pra = (torch.tensor([v]) for v in C.primer_from_name("C"))
+    args = (f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], pr, prr, pra)
+    lo = m.generate_batch(*args, target_seq_length=T, beam=0, uniforms=torch.zeros(T, B))
+    # with token 0 and a doubled previous id suppressed, u = 0 alternates between the two lowest ids
+    assert set(lo[:, 1:].flatten().tolist()) <= {1, 2}
+    uh = torch.full((T, B), 1.0 - 2.0 ** -24)
+    hi, hl = m.generate_batch(*args, target_seq_length=T, beam=0, uniforms=uh, return_logits=True)
+    _check_draws(hi, hl, uh, 1, 0, 2)          # the top of the CDF: the last ids that still carry mass above fp32 rounding
+    assert int(hi[:, 1:].min()) > 100
+    torch.manual_seed(11)
+    a = m.generate_batch(*args, target_seq_length=T, beam=0)
+    torch.manual_seed(11)
+    b = m.generate_batch(*args, target_seq_length=T, beam=0)
+    assert torch.equal(a, b) and int(a[:, 1:].min()) >= 1
+    mn = m.generate_batch(*args, target_seq_length=T, beam=0, sampler="multinomial")
+    assert int(mn[:, 1:].min()) >= 1 and int(mn.max()) < C.CHORD_END
+    assert not bool(((mn[:, 2:] == mn[:, 1:-1]) & (mn[:, 1:-1] == mn[:, :-2])).any())

@@ -36,6 +36,7 @@ SIGNATURES = {
     "amt_encode": [_P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P],
     "amt_prefill": [_P, _I, _I, _P, _P, _P, _P, _P, _I, _P],
     "amt_generate_begin": [_P, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P],
+    "amt_generate_set_uniforms": [_P, _P, _P],
     "amt_generate_run": [_P, _I, _P, _P],
     "amt_generate_profile": [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _P],
     "amt_generate_step_probs": [_P, _P, _P],

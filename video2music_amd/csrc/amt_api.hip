@@ -95,6 +95,8 @@ struct amt_handle {
     float *tab_r = nullptr, *tab_a = nullptr, *tab_k = nullptr, *tab_p = nullptr, *tab_cb = nullptr;
     int* pos = nullptr;
     unsigned* ticket = nullptr;
+    float* unif = nullptr;               // [Tcap][maxB] uniforms of the device-side categorical draw (amt_generate_set_uniforms)
+    int use_unif = 0;
     int64_t *tokens = nullptr, *roots = nullptr, *attrs = nullptr;   // [maxB][Tcap]
     // current generation
     int genB = 0, genT = 0, genP = 0, beam = 0, mcN = 0, mcC = 2, steps_done = 0;
@@ -210,6 +212,7 @@ SampleParams sample_params(amt_handle* h, float* logits_out, float* probs_out, i
     p.logits_out = logits_out; p.probs_out = probs_out;
     p.key = h->keyb; p.PR = h->PR; p.PA = h->PA; p.wkey = h->wkey; p.cbias = W(h, "Linear_chord.bias"); p.pe = h->pe;
     p.x_next = h->x_in; p.sample_external = external;
+    p.uniforms = h->use_unif ? h->unif : nullptr;
     if (h->fold) {
         p.lraw = h->lraw; p.ld_lraw = VS; p.h1 = h->vs; p.h2 = h->vs + VS; p.h3 = h->vs + 3 * VS; p.h4 = h->vs + 4 * VS;
         p.tab_r = h->tab_r; p.tab_a = h->tab_a; p.tab_k = h->tab_k; p.tab_p = h->tab_p;
@@ -387,7 +390,7 @@ int32_t enqueue_decoder_step(amt_handle* h, hipStream_t s, StepProf* prof = null
 }
 
 int32_t get_graph(amt_handle* h, int nsteps, float* logits_out, hipGraphExec_t* out) {
-    amt_handle::GraphKey key{h->genB, h->genT, h->genP, h->beam, h->mcN, h->mcC, h->encS, nsteps, h->skip_mask, 0, logits_out};
+    amt_handle::GraphKey key{h->genB, h->genT, h->genP, h->beam, h->mcN, h->mcC, h->encS, nsteps, h->skip_mask, h->use_unif, logits_out};
     for (auto& g : h->graphs)
         if (memcmp(&g.key, &key, sizeof(key)) == 0) { *out = g.exec; return 0; }
     hipGraph_t graph;
@@ -580,6 +583,7 @@ extern "C" int32_t amt_finalize(amt_handle* h) {
         if ((rc = dev_alloc(h, &h->keyb, (size_t)32))) return rc;
         if ((rc = dev_alloc(h, &h->pos, (size_t)4))) return rc;
         if ((rc = dev_alloc(h, &h->ticket, (size_t)4))) return rc;
+        if ((rc = dev_alloc(h, &h->unif, (size_t)h->maxB * h->Tcap))) return rc;
         if ((rc = dev_alloc(h, &h->tokens, (size_t)h->maxB * h->Tcap))) return rc;
         if ((rc = dev_alloc(h, &h->roots, (size_t)h->maxB * h->Tcap))) return rc;
         if ((rc = dev_alloc(h, &h->attrs, (size_t)h->maxB * h->Tcap))) return rc;
@@ -777,7 +781,7 @@ extern "C" int32_t amt_generate_begin(amt_handle* h, int32_t B, const int64_t* p
     AMT_CHECK_ARG(primer && primer_root && primer_attr && key, "amt_generate: null pointer");
     hipStream_t s = (hipStream_t)stream;
     h->genB = B; h->genT = T; h->genP = P; h->beam = beam; h->mcN = max_conseq_N; h->mcC = max_conseq_chord;
-    h->steps_done = 0; h->gen_active = true;
+    h->steps_done = 0; h->gen_active = true; h->use_unif = 0;
     hipLaunchKernelGGL(init_sequences_kernel, dim3(B), dim3(256), 0, s, h->tokens, h->roots, h->attrs, primer, primer_root,
                        primer_attr, P, primer_per_clip, T);
     AMT_LAUNCH_CHECK();
@@ -785,6 +789,15 @@ extern "C" int32_t amt_generate_begin(amt_handle* h, int32_t B, const int64_t* p
     AMT_HIP(hipMemsetAsync(h->pos, 0, 16, s));
     AMT_HIP(hipMemsetAsync(h->ticket, 0, 16, s));
     return amt_launch_embed_step(sample_params(h, nullptr, nullptr, 0), 0, s);     // x_in for position 0
+}
+
+extern "C" int32_t amt_generate_set_uniforms(amt_handle* h, const float* uniforms, void* stream) {
+    AMT_CHECK_ARG(h && h->gen_active, "amt_generate_set_uniforms: no generation in progress");
+    AMT_CHECK_ARG(h->beam == 0, "amt_generate_set_uniforms: the categorical draw belongs to the sampling branch (beam=0)");
+    h->use_unif = uniforms != nullptr;
+    if (uniforms)
+        AMT_HIP(hipMemcpyAsync(h->unif, uniforms, (size_t)h->genT * h->genB * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
 }
 
 extern "C" int32_t amt_generate_run(amt_handle* h, int32_t n_steps, float* logits_out, void* stream) {

@@ -171,6 +171,9 @@ struct SampleParams {
     const float* key; const float* PR; const float* PA; const float* wkey; const float* cbias; const float* pe;
     float* x_next;                   // [B][d]
     int sample_external;             // 1: do not pick a token (host samples from probs_out), only write probs
+    // beam == 0 with uniforms != null: draw the token from the decision distribution by inverse CDF with the uniform
+    // uniforms[pos*B + b] in [0,1) (the reference's Categorical.sample, :1104-1105); null: arg-max (oracle G2)
+    const float* uniforms;
     // Folded output head (lraw != null): the last skinny GEMM already produced lraw = u . (Wout o g3 o gf)^T (ld_lraw
     // floats per clip); with the statistics (mu, rstd) of u and (m2, rstd2) of LayerNorm3(u) the logits are
     //   rstd2 * (rstd * (lraw - mu*h1) + h2 - m2*h3) + h4      (h1..h4: [159] vectors built at weight load)

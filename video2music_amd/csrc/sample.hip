@@ -65,6 +65,47 @@ __device__ __forceinline__ void advance_pos(const SampleParams& p, int t) {
     }
 }
 
+// The decision of one clip by one wave: pr[k] = (masked, un-normalised) probability of token lane + 64k, ps their sum.
+// Arg-max of pr / ps (ties -> lowest id), or, with uniforms, the inverse-CDF draw: the first token whose cumulative
+// probability reaches u * ps (tokens are ordered lane-major inside k = 0, 1, 2).
+__device__ __forceinline__ int pick_token(const SampleParams& p, const float (&pr)[3], float ps, int lane, int b, int t) {
+    if (p.beam == 0 && p.uniforms) {
+        const float target = p.uniforms[(size_t)t * p.B + b] * ps;
+        float base = 0.f;
+        int tok = -1, last = -1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float c = pr[k];                                   // inclusive scan over the wave
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float up = __shfl_up(c, off, 64);
+                if (lane >= off) c += up;
+            }
+            const unsigned long long hit = __ballot(pr[k] > 0.f && base + c >= target);
+            const unsigned long long pos = __ballot(pr[k] > 0.f);
+            if (tok < 0 && hit) tok = 64 * k + __ffsll((long long)hit) - 1;
+            if (pos) last = 64 * k + 63 - __clzll((long long)pos);
+            base += __shfl(c, 63, 64);
+        }
+        return tok >= 0 ? tok : (last >= 0 ? last : 0);        // rounding at u -> 1: the last token with positive mass
+    }
+    float bv = -1.f;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int n = lane + 64 * k;
+        const float pn = (p.beam == 0) ? pr[k] / ps : pr[k];   // Categorical normalises its probs
+        if (n < VP && pn > bv) { bv = pn; bi = n; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    return bi;
+}
+
 template <int KCH>       // float4 chunks per lane covering d (d <= KCH*256)
 __global__ __launch_bounds__(NWS * 64) void sample_kernel(SampleParams p) {
     __shared__ __attribute__((aligned(16))) float ys[1024];
@@ -215,20 +256,7 @@ __global__ __launch_bounds__(NWS * 64) void sample_kernel(SampleParams p) {
             for (int k = 0; k < 3; ++k)
                 if (lane + 64 * k < VP) p.probs_out[(size_t)b * VP + lane + 64 * k] = pr[k];
         }
-        float bv = -1.f;
-        int bi = 0x7fffffff;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int n = lane + 64 * k;
-            const float pn = (p.beam == 0) ? pr[k] / ps : pr[k];   // Categorical normalises its probs
-            if (n < VP && pn > bv) { bv = pn; bi = n; }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
+        const int bi = pick_token(p, pr, ps, lane, b, t);
         if (lane == 0) s_tok = bi;
     }
     __syncthreads();
@@ -355,20 +383,7 @@ __global__ __launch_bounds__(256) void sample_fold_kernel(SampleParams p) {
             for (int k = 0; k < 3; ++k)
                 if (lane + 64 * k < VP) p.probs_out[(size_t)b * VP + lane + 64 * k] = pr[k];
         }
-        float bv = -1.f;
-        int bi = 0x7fffffff;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int n = lane + 64 * k;
-            const float pn = (p.beam == 0) ? pr[k] / ps : pr[k];   // Categorical normalises its probs
-            if (n < VP && pn > bv) { bv = pn; bi = n; }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
+        const int bi = pick_token(p, pr, ps, lane, b, t);
         if (lane == 0) s_tok = bi;
     }
     __syncthreads();

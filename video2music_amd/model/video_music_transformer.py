@@ -10,7 +10,8 @@ non-GPU module raises.
 
 Differences a caller can observe, all additive:
   * ``generate`` accepts ``sampler="categorical"`` (default; the reference's
-    ``Categorical.sample``, drawn with ``torch.multinomial`` on device) or ``"argmax"`` (the
+    ``Categorical.sample``, drawn inside the decode graph by inverse CDF from ``torch.rand`` uniforms),
+    ``"multinomial"`` (same distribution, ``torch.multinomial`` per step) or ``"argmax"`` (the
     deterministic feedback-greedy decode used for parity, oracle G2);
   * ``generate_batch`` runs B clips at once (the reference is hard-wired to one clip,
     ``:1059-1061``); per clip the result equals a B=1 ``generate``;
@@ -317,12 +318,15 @@ class VideoMusicTransformer(nn.Module):
 
     def generate_batch(self, feature_semantic_list, feature_key, feature_scene_offset, feature_motion, feature_emotion,
                        primer, primer_root, primer_attr, target_seq_length=300, beam=0, beam_chance=1.0,
-                       max_conseq_N=0, max_conseq_chord=2, sampler="categorical", return_logits=False, one_pass_top1=True):
+                       max_conseq_N=0, max_conseq_chord=2, sampler="categorical", return_logits=False, one_pass_top1=True,
+                       uniforms=None):
         """Batched generate: features (B,S,·), primer (P,) shared or (B,P) per clip -> LongTensor (B,T).
 
         beam=1 is the reference's deterministic top-1 branch (oracle G1; generated ids never feed
-        back, :1078-1084).  beam=0 is the sampling branch (:1085-1128) with
-        ``sampler="categorical"`` (random, torch RNG) or ``"argmax"`` (oracle G2).
+        back, :1078-1084).  beam=0 is the sampling branch (:1085-1128) with ``sampler="categorical"`` (the reference's
+        Categorical draw, done on device inside the captured step graph by inverse CDF from ``uniforms`` (T,B) -- default
+        ``torch.rand`` on the model's device, so ``torch.manual_seed`` makes a run repeatable), ``"multinomial"`` (the
+        same distribution drawn per step on the host side with ``torch.multinomial``) or ``"argmax"`` (oracle G2).
 
         In the beam=1 branch the model input of every generated position is the PAD root/attr pair, so all T-1 decisions
         follow from ONE teacher-forced forward over (primer, PAD, PAD, ...): ``one_pass_top1`` (default) does exactly that
@@ -333,7 +337,7 @@ class VideoMusicTransformer(nn.Module):
             raise NotImplementedError("beam > 1 is not implemented (generate.py:347-349 asserts it out as well)")
         if beam == 1 and beam_chance < 1.0:
             raise NotImplementedError("beam_chance < 1 mixes the two branches at random; not a parity target")
-        if sampler not in ("categorical", "argmax"):
+        if sampler not in ("categorical", "multinomial", "argmax"):
             raise ValueError(f"unknown sampler {sampler!r}")
         h = self._ensure_handle()
         dev = self._device()
@@ -370,7 +374,12 @@ class VideoMusicTransformer(nn.Module):
             st = _lib.stream_ptr()
             _lib.call("amt_generate_begin", h, nb, _lib.ptr(pr[0]), _lib.ptr(pr[1]), _lib.ptr(pr[2]), P, int(per_clip),
                       _lib.ptr(key[sl].contiguous()), T, beam, int(max_conseq_N), int(max_conseq_chord), st)
-            if beam == 1 or sampler == "argmax":
+            if beam == 1 or sampler in ("argmax", "categorical"):
+                if beam == 0 and sampler == "categorical":
+                    u = (torch.rand(T, nb, device=dev) if uniforms is None
+                         else torch.as_tensor(uniforms, dtype=torch.float32, device=dev)[:, sl].contiguous())
+                    assert u.shape == (T, nb), "uniforms must be (T, B)"
+                    _lib.call("amt_generate_set_uniforms", h, _lib.ptr(u), st)
                 _lib.call("amt_generate_run", h, -1, _lib.ptr(lg), st)
             else:
                 probs = torch.empty(nb, CHORD_END, device=dev)

@@ -53,6 +53,7 @@ def parse_generate_args(argv=None):
                         help="also write <id>_chords.mid (voiced arpeggios, velocities from the regression head when --regression is set; "
                              "generate.py:446-607)")
     parser.add_argument("--v2_streams", type=int, default=8, help="clips of a V2 run decoded concurrently (one stream + thread each)")
-    parser.add_argument("--sampler", type=str, default="categorical", choices=["categorical", "argmax"])
+    parser.add_argument("--sampler", type=str, default="categorical", choices=["categorical", "multinomial", "argmax"],
+                        help="beam=0 decision: categorical = on-device draw (default), multinomial = host torch.multinomial per step, argmax")
     parser.add_argument("--seed", type=int, default=1234)
     return parser.parse_known_args(argv)
