@@ -223,8 +223,9 @@ int32_t amt_moe_combine_fwd(const float* y_rows, const int32_t* slot_pos, const 
  * SharedMoE(top-2), post-norm LayerNorms; decoder.norm; Wout -> logits_out[159].
  * Every projection handles one row, so it runs on the skinny decode GEMM over weights packed once by
  * amt_pack_weight_fwd (out: ceil(N/16)*16*K floats; the experts of a MoE layer are packed one after the other).
- * tab: device pointers, 10 global (PR, PA, wkey, Linear_chord.bias, rope cache (max_seq, E/2, 2), decoder.norm w, b,
- * packed Wout, Wout b, an int32 pair {0, 1}) then 32 per layer (packed self in_proj, its bias, packed out_proj, b,
+ * tab: device pointers, 11 global (PR, PA, wkey, Linear_chord.bias, rope cache (max_seq, E/2, 2) or null = no rotation,
+ * decoder.norm w, b, packed Wout, Wout b, an int32 pair {0, 1}, learned positional table (max_seq, E) added to the
+ * embedding of position t or null: version '2.0' has the table and no rotation, :375-380,497-503) then 32 per layer (packed self in_proj, its bias, packed out_proj, b,
  * norm1 w, b, packed cross in_proj rows 0:E, its bias, packed out_proj, b, norm2 w, b, norm3 w, b, self K cache, V cache
  * (head-major: H, max_seq, hd), cross K (roped), V (head-major: H, S, hd), router w (null = plain GLU layer), router b, packed linear1, b, packed gate, b,
  * packed linear2, b (per expert, stacked, for a MoE layer), shared expert's six tensors (packed weights) or null).

@@ -1,0 +1,76 @@
+"""Golden fixtures of the other VideoMusicTransformer_V2 variants, from the REFERENCE class
+itself on CPU: version '2.0' (learned positional tables, no RoPE), '2.1' (top-k scheduler: training only), and '2.2' with
+chord_embed=True (chord ids through a frozen table).
+
+TEST INFRASTRUCTURE; runs only in the build container:  PYTHONDONTWRITEBYTECODE=1 python oracle/make_goldens_v2x.py
+
+chord_embed=True loads a gensim Word2Vec file the tree does not ship (video_music_transformer.py:340-344), so the model is
+built with chord_embed=False and the two attributes that branch would have set (`chord_embed`, `chord_embedding_model`)
+are assigned afterwards with a procedural (159, d) table -- the forward/generate code that runs is the reference's.
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import make_goldens as MG                                   # noqa: E402  (import recipe, procedural weights)
+from video2music_amd import synthetic                       # noqa: E402
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_grad_enabled(False)
+    ref = MG.import_reference()
+    from torch.distributions.categorical import Categorical
+    orig_sample = Categorical.sample
+    t = MG.t
+    feats = synthetic.synthetic_features(3, seed=1234)
+    key = np.array([[0.0], [1.0], [0.0]], dtype=np.float32)
+    out = {}
+    for tag, version, chord_embed in (("v20", "2.0", False), ("v21", "2.1", False), ("v22ce", "2.2", True)):
+        cfg = dict(version_name=version, n_layers=6, num_heads=4, d_model=128, dim_feedforward=256, max_sequence_chord=300,
+                   total_vf_dim=synthetic.total_vf_dim(1))
+        m = ref.vmt.VideoMusicTransformer_V2(**cfg).eval()
+        MG.load_synthetic(m, seed=0)
+        if chord_embed:
+            table = torch.from_numpy(synthetic.fill_tensor("chord_embedding_model.weight", (159, 128), 0))
+            m.chord_embed = True
+            m.chord_embedding_model = torch.nn.Embedding.from_pretrained(table, freeze=True)
+        rs = np.random.RandomState(29)
+        for B in (1, 2):
+            L = 12
+            ids = rs.randint(0, 157, size=(B, L)).astype(np.int64)
+            rootv = rs.randint(0, 13, size=(B, L)).astype(np.int64)
+            attrv = rs.randint(0, 14, size=(B, L)).astype(np.int64)
+            sl = slice(0, B)
+            y = m(t(ids), t(rootv), t(attrv), t(feats["semantic"][sl]), t(key[sl]), t(feats["scene_offset"][sl]),
+                  t(feats["motion"][sl]), t(feats["emotion"][sl]))
+            out[f"{tag}_x_B{B}"], out[f"{tag}_root_B{B}"], out[f"{tag}_attr_B{B}"], out[f"{tag}_logits_B{B}"] = ids, rootv, attrv, y.numpy()
+        kw = dict(feature_semantic_list=t(feats["semantic"][:1]), feature_key=t(key[0]), feature_scene_offset=t(feats["scene_offset"][:1]),
+                  feature_motion=t(feats["motion"][:1]), feature_emotion=t(feats["emotion"][:1]),
+                  primer=torch.tensor([1]), primer_root=torch.tensor([1]), primer_attr=torch.tensor([0]), target_seq_length=24)
+        out[f"{tag}_g1"] = m.generate(beam=1, beam_chance=1.0, **kw).numpy()
+        margins = []
+
+        def argmax_sample(self, sample_shape=torch.Size()):
+            top2 = torch.topk(self.probs.flatten(), 2)[0]
+            margins.append(float(top2[0] - top2[1]))
+            return self.probs.argmax(-1)
+
+        Categorical.sample = argmax_sample
+        try:
+            out[f"{tag}_g2"] = m.generate(beam=0, **kw).numpy()
+            out[f"{tag}_g2_t"] = m.generate(beam=0, temperature=0.7, **kw).numpy()
+        finally:
+            Categorical.sample = orig_sample
+        out[f"{tag}_g2_margins"] = np.array(margins, dtype=np.float64)
+        print(tag, "G1 unique", len(set(out[f"{tag}_g1"].flatten().tolist())), "G2 unique", len(set(out[f"{tag}_g2"].flatten().tolist())),
+              "min margin", min(margins))
+    np.savez_compressed(os.path.join(MG.OUT, "g_v2_variants.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

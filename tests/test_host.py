@@ -61,7 +61,12 @@ def test_v2_state_dict_matches_reference_key_set():
     m = VideoMusicTransformer_V2(**CFG_V2)
     assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == dict(v2_named_shapes(**CFG_V2))
     with pytest.raises(NotImplementedError):
-        VideoMusicTransformer_V2(version_name="2.0", total_vf_dim=1287)
+        VideoMusicTransformer_V2(version_name="2.3", total_vf_dim=1287)
+    # '2.0': learned positional tables instead of RoPE (the default version_name of the class, :317)
+    v20 = VideoMusicTransformer_V2(**dict(CFG_V2, version_name="2.0", max_sequence_chord=64))
+    extra = set(v20.state_dict()) - set(m.state_dict())
+    assert extra == {"positional_embedding.weight", "positional_embedding_video.weight"}
+    assert v20.positional_embedding.weight.shape == (64, CFG_V2["d_model"]) and v20._rope_cache is None
 
 
 def test_unsupported_constructor_options_raise():

@@ -104,3 +104,61 @@ def test_cli_decodes_several_v2_clips_concurrently(tmp_path):
     a = G.main(base + ["-output_dir", str(tmp_path / "a"), "--v2_streams", "1"]).cpu()
     b = G.main(base + ["-output_dir", str(tmp_path / "b"), "--v2_streams", "4"]).cpu()
     assert a.shape == (6, 40) and torch.equal(a, b)
+
+
+# ---- the other V2 variants: '2.0' (learned positional tables, no RoPE), '2.1', and chord_embed=True -----------------
+def _variant(version, chord_embed=False, **extra):
+    cfg = dict(CFG_V2, version_name=version, chord_embed=chord_embed, **extra)
+    m = VideoMusicTransformer_V2(**cfg).eval()
+    shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=0).items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected
+    return m.cuda()
+
+
+@pytest.mark.parametrize("tag,version,ce", [("v20", "2.0", False), ("v21", "2.1", False), ("v22ce", "2.2", True)])
+def test_v2_variants_vs_reference_golden(golden, tag, version, ce):
+    g = golden("g_v2_variants.npz")
+    m = _variant(version, ce, rms_norm=(version == "2.1"))          # rms_norm has no effect in V2, as in the reference
+    assert ("positional_embedding.weight" in m.state_dict()) == (version == "2.0")
+    assert ("chord_embedding_model.weight" in m.state_dict()) == ce
+    key = np.array([[0.0], [1.0], [0.0]], dtype=np.float32)
+    feats = synthetic.synthetic_features(3, seed=1234)
+    for B in (1, 2):
+        f = {k: v.cuda() for k, v in feats_t(feats, slice(0, B), key=key).items()}
+        x, root, attr = (torch.from_numpy(g[f"{tag}_{n}_B{B}"]) for n in ("x", "root", "attr"))
+        with torch.no_grad():
+            y = m(x, root, attr, f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"])
+        err = np.abs(y.cpu().numpy() - g[f"{tag}_logits_B{B}"]).max()
+        assert err < 1e-3, (tag, B, err)
+    f = {k: v.cuda() for k, v in feats_t(feats, slice(0, 1), key=key).items()}
+    kw = dict(feature_semantic_list=f["semantic"], feature_key=f["key"][0], feature_scene_offset=f["scene_offset"],
+              feature_motion=f["motion"], feature_emotion=f["emotion"], primer=torch.tensor([1]), primer_root=torch.tensor([1]),
+              primer_attr=torch.tensor([0]), target_seq_length=24)
+    with torch.no_grad():
+        assert np.array_equal(m.generate(beam=1, **kw).cpu().numpy(), g[f"{tag}_g1"])
+        for graph in (True, False):
+            assert np.array_equal(m.generate(beam=0, sampler="argmax", use_graph=graph, **kw).cpu().numpy(), g[f"{tag}_g2"])
+        assert np.array_equal(m.generate(beam=0, sampler="argmax", temperature=0.7, **kw).cpu().numpy(), g[f"{tag}_g2_t"])
+        assert np.array_equal(m.generate(beam=0, sampler="argmax", use_cache=False, **kw).cpu().numpy(), g[f"{tag}_g2"])
+
+
+def test_v2_version_21_equals_22_in_eval(golden):
+    assert np.array_equal(golden("g_v2_variants.npz")["v21_g2"], golden("g_v2_cfg1.npz")["g2"])
+
+
+def test_v2_chord_table_rows_follow_the_state_dict():
+    """The frozen chord table comes from a Word2Vec file in the reference; its row count is whatever that file holds."""
+    m = VideoMusicTransformer_V2(**dict(CFG_V2, chord_embed=True)).eval()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["chord_embedding_model.weight"] = torch.randn(170, CFG_V2["d_model"])
+    m.load_state_dict(sd)
+    assert m.chord_embedding_model.weight.shape == (170, CFG_V2["d_model"]) and not m.chord_embedding_model.weight.requires_grad
+
+
+def test_v2_unbuilt_variants_say_so():
+    with pytest.raises(NotImplementedError):
+        VideoMusicTransformer_V2(**dict(CFG_V2, version_name="2.3"))
+    with pytest.raises(NotImplementedError):
+        VideoMusicTransformer_V2(**dict(CFG_V2, dropTokenRate=0.1))

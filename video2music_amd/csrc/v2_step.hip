@@ -16,22 +16,24 @@
 
 namespace {
 
-constexpr int G_PTRS = 10, L_PTRS = 32;
-enum { G_PR, G_PA, G_WKEY, G_CBIAS, G_ROPE, G_FNW, G_FNB, G_WOUT, G_BOUT, G_SLOT01 };
+constexpr int G_PTRS = 11, L_PTRS = 32;
+enum { G_PR, G_PA, G_WKEY, G_CBIAS, G_ROPE, G_FNW, G_FNB, G_WOUT, G_BOUT, G_SLOT01, G_PE };
 enum { L_SAW, L_SAB, L_SAOW, L_SAOB, L_N1W, L_N1B, L_CAW, L_CAB, L_CAOW, L_CAOB, L_N2W, L_N2B, L_N3W, L_N3B,
        L_KC, L_VC, L_KX, L_VX, L_GATEW, L_GATEB, L_W1, L_B1, L_WG, L_BG, L_W2, L_B2, L_SW1, L_SB1, L_SWG, L_SBG, L_SW2, L_SB2 };
 
 // (root, attr) either as launch arguments or, for a captured step graph, from device memory (tok[0], tok[1])
 __global__ void embed_one_kernel(int root, int attr, const int* __restrict__ tok, float kv, const float* __restrict__ PR,
                                  const float* __restrict__ PA, const float* __restrict__ wkey, const float* __restrict__ bias,
-                                 float* __restrict__ out, int d) {
-    if (tok) { root = tok[0]; attr = tok[1]; }
+                                 float* __restrict__ out, int d, const float* __restrict__ pe, int t) {
+    if (tok) { root = tok[0]; attr = tok[1]; t = tok[-1]; }      // device state {position, root, attr}
+    if (pe) pe += (size_t)t * d;                                 // learned positional row (version '2.0' / V1), else none
     for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
         const float4 pr = ld4(PR + (size_t)root * d + c), pa = ld4(PA + (size_t)attr * d + c);
         const float4 wk = ld4(wkey + c), bb = ld4(bias + c);
-        float4 o;        // the summation order of chord_embed_kernel with a zero positional row
-        o.x = ((pr.x + pa.x) + kv * wk.x + bb.x) + 0.f; o.y = ((pr.y + pa.y) + kv * wk.y + bb.y) + 0.f;
-        o.z = ((pr.z + pa.z) + kv * wk.z + bb.z) + 0.f; o.w = ((pr.w + pa.w) + kv * wk.w + bb.w) + 0.f;
+        const float4 pp = pe ? ld4(pe + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 o;        // the summation order of chord_embed_kernel
+        o.x = ((pr.x + pa.x) + kv * wk.x + bb.x) + pp.x; o.y = ((pr.y + pa.y) + kv * wk.y + bb.y) + pp.y;
+        o.z = ((pr.z + pa.z) + kv * wk.z + bb.z) + pp.z; o.w = ((pr.w + pa.w) + kv * wk.w + bb.w) + pp.w;
         st4(out + c, o);
     }
 }
@@ -141,9 +143,10 @@ extern "C" int32_t amt_v2_step(const void* const* tab, int32_t n_layers, int32_t
     // and increments the position at its end, so one captured graph serves every token
     const int* pos = (const int*)state_dev;
     const int* tok = pos ? pos + 1 : nullptr;
-    hipLaunchKernelGGL(embed_one_kernel, dim3(1), dim3(128), 0, s, root, attr, tok, key, G(G_PR), G(G_PA), G(G_WKEY), G(G_CBIAS), x, E);
+    hipLaunchKernelGGL(embed_one_kernel, dim3(1), dim3(128), 0, s, root, attr, tok, key, G(G_PR), G(G_PA), G(G_WKEY), G(G_CBIAS), x, E, G(G_PE), t);
     AMT_LAUNCH_CHECK();
-    const float* rope_row = pos ? G(G_ROPE) : G(G_ROPE) + (size_t)t * E;    // cache row t: E/2 (cos, sin) pairs
+    // cache row t: E/2 (cos, sin) pairs; no table (null) = no rotation (version '2.0' / the V1 family)
+    const float* rope_row = !G(G_ROPE) ? nullptr : pos ? G(G_ROPE) : G(G_ROPE) + (size_t)t * E;
     for (int l = 0; l < n_layers; ++l) {
         const void* const* L = tab + G_PTRS + (size_t)l * L_PTRS;
         auto P = [&](int i) { return (const float*)L[i]; };

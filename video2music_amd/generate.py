@@ -65,8 +65,9 @@ def main(argv=None):
     args = parse_generate_args(argv)[0]
     if args.music_gen_version in ("None", "none", ""):
         args.music_gen_version = None
-    if args.music_gen_version not in (None, "2.2"):
-        raise SystemExit("built: music_gen_version None (base AMT) and '2.2' (VideoMusicTransformer_V2); the other V1/V2/V3 variants are SURVEY.md §8 row f1")
+    if args.music_gen_version is not None and not args.music_gen_version.startswith("2."):
+        raise SystemExit("built: music_gen_version None (base AMT) and the '2.x' family (VideoMusicTransformer_V2: 2.0, 2.1, 2.2); "
+                         "V1 / V3 are SURVEY.md §8 row f1")
     if args.force_cpu:
         raise SystemExit("--force_cpu: video2music_amd has no CPU path (the CPU oracle lives in oracle/ for tests only)")
     rank, world, local = vdist.init()

@@ -398,7 +398,7 @@ class VideoMusicTransformer(nn.Module):
 
 
 # ==================================================================================================
-# VideoMusicTransformer_V2, version '2.2' (the reference's default music_gen_version)
+# VideoMusicTransformer_V2, versions '2.0' / '2.1' / '2.2' (2.2 = the reference's default music_gen_version)
 # ==================================================================================================
 class _DecoderLayerV2(nn.Module):
     """Keys of custom_transformer.TransformerDecoderLayer (model/custom_transformer.py:1250-1292)."""
@@ -437,22 +437,30 @@ class _TransformerParamsV2(nn.Module):
 
 
 class VideoMusicTransformer_V2(nn.Module):
-    """Reference ``VideoMusicTransformer_V2`` (model/video_music_transformer.py:316-609) for ``version_name='2.2'``:
-    no additive positional encoding, RoPE (cache built for dim=d_model, applied through the raw (H, L, B, hd) view)
-    inside every attention, three GLU feed-forward layers then three SharedMoELayer(6 experts, top-2) layers in both
-    stacks, post-norm.  A composition of the library's operator kernels (``video2music_amd/ops.py``): ``generate`` runs the
-    video encoder once and the decoder one token at a time over cached keys/values (the reference re-runs both stacks
-    on the whole prefix every step, :547-548).
+    """Reference ``VideoMusicTransformer_V2`` (model/video_music_transformer.py:316-609), versions '2.2' (generate.py's
+    default), '2.1' (same network in eval: its top-k scheduler acts in training only) and '2.0':
+    RoPE (cache built for dim=d_model, applied through the raw (H, L, B, hd) view) inside every attention and no additive
+    positional encoding -- or, for '2.0', learned positional tables and no rotation; three GLU feed-forward layers then
+    three SharedMoELayer(6 experts, top-2) layers in both stacks, post-norm; optionally ``chord_embed=True`` (chord ids
+    through a frozen table, the configuration of the Video2music app).  A composition of the library's operator kernels
+    (``video2music_amd/ops.py``): ``generate`` runs the video encoder once and the decoder one token at a time over
+    cached keys/values (the reference re-runs both stacks on the whole prefix every step, :547-548).
     """
 
     def __init__(self, version_name="2.0", n_layers=6, num_heads=8, d_model=512, dim_feedforward=1024, dropout=0.1,
                  max_sequence_midi=2048, max_sequence_video=300, max_sequence_chord=300, total_vf_dim=0, rms_norm=False,
                  scene_embed=False, chord_embed=False, dropTokenRate=0.0, balancing=False):
         super().__init__()
-        if version_name != "2.2":
-            raise NotImplementedError("only version_name='2.2' (generate.py's default) is built; 2.0 / 2.1 / 2.3 are variants of it")
-        if scene_embed or chord_embed or dropTokenRate != 0.0 or rms_norm:
-            raise NotImplementedError("scene_embed / chord_embed / dropTokenRate / rms_norm are outside this path")
+        # the reference matches version strings with `in ('2.0')` -- a substring test on a str -- for the learned
+        # positional tables (:375,497) and with tuple membership for RoPE (:379); both rules are kept as they are
+        self._learned_pos = version_name in "2.0"
+        self._use_rope = (not self._learned_pos) and version_name in ("2.1", "2.2", "2.3")
+        if version_name in "2.3":
+            raise NotImplementedError("version '2.3' swaps the experts for efficient_kan.KANLinear, a package the reference does not vendor")
+        if scene_embed or dropTokenRate != 0.0:
+            raise NotImplementedError("scene_embed / dropTokenRate (a random mask applied even in eval, :484-488) are outside this path")
+        # rms_norm is accepted and has no effect, as in the reference (its RMSNorm branch is commented out, :364-371);
+        # '2.1' differs from '2.2' by a top-k scheduler that only acts in training (moe.py:232-236)
         if n_layers < 3:
             raise ValueError("the reference builds 3 shallow + (n_layers-3) deep layers")
         self.nlayers, self.nhead, self.d_model, self.d_ff, self.dropout = n_layers, num_heads, d_model, dim_feedforward, dropout
@@ -460,19 +468,42 @@ class VideoMusicTransformer_V2(nn.Module):
         self.scene_embed, self.chord_embed, self.dropTokenRate, self.version_name = scene_embed, chord_embed, dropTokenRate, version_name
         self.total_vf_dim = total_vf_dim
         self.n_experts, self.n_experts_per_token = 6, 2
+        if chord_embed:
+            # the reference fills this frozen table from a gensim Word2Vec file (:340-344); here it arrives with the
+            # state_dict (key chord_embedding_model.weight, any number of rows >= the ids fed; vector size = d_model)
+            self.chord_embedding_model = nn.Embedding(CHORD_SIZE, d_model)
+            self.chord_embedding_model.weight.requires_grad_(False)
+            self._register_load_state_dict_pre_hook(self._resize_chord_table)
         self.embedding = nn.Embedding(CHORD_SIZE, d_model)
         self.embedding_root = nn.Embedding(CHORD_ROOT_SIZE, d_model)
         self.embedding_attr = nn.Embedding(CHORD_ATTR_SIZE, d_model)
         self.Linear_vis = nn.Linear(total_vf_dim, d_model)
         self.Linear_chord = nn.Linear(d_model + 1, d_model)
         self.condition_linear = nn.Linear(1, d_model)
+        if self._learned_pos:
+            self.positional_embedding = nn.Embedding(max_sequence_chord, d_model)
+            self.positional_embedding_video = nn.Embedding(max_sequence_video, d_model)
         self.transformer = _TransformerParamsV2(d_model, num_heads, n_layers, dim_feedforward, dropout, self.n_experts, balancing)
         self.Wout = nn.Linear(d_model, CHORD_SIZE)
         self.softmax = nn.Softmax(dim=-1)
-        from .rotate_operation import RotaryPositionalEmbeddings
-        rope = RotaryPositionalEmbeddings(d_model, max_sequence_video)      # dim = d_model, not head_dim (:380)
-        self.register_buffer("_rope_cache", rope.cache.clone(), persistent=False)
+        if self._use_rope:
+            from .rotate_operation import RotaryPositionalEmbeddings
+            rope = RotaryPositionalEmbeddings(d_model, max_sequence_video)      # dim = d_model, not head_dim (:380)
+            self.register_buffer("_rope_cache", rope.cache.clone(), persistent=False)
+        else:
+            self._rope_cache = None
+        # longest chord sequence: the RoPE cache caps it at max_sequence_video (rotate_operation.py:148), the learned
+        # table at max_sequence_chord; with neither there is no cap but the caches need a size
+        self._max_dec = max_sequence_video if self._use_rope else max_sequence_chord
         self._derived_sig = None
+
+    def _resize_chord_table(self, state_dict, prefix, *_):
+        w = state_dict.get(prefix + "chord_embedding_model.weight")
+        if w is not None and tuple(w.shape) != tuple(self.chord_embedding_model.weight.shape):
+            if w.dim() != 2 or w.shape[1] != self.d_model:
+                raise ValueError("chord_embedding_model.weight must be (n_chords, d_model)")
+            cur = self.chord_embedding_model.weight
+            self.chord_embedding_model.weight = nn.Parameter(torch.empty(w.shape, dtype=cur.dtype, device=cur.device), requires_grad=False)
 
     # ---- derived tensors (rebuilt when a parameter changes): Linear_chord tables, padded Linear_vis ----
     def _derived(self):
@@ -480,20 +511,31 @@ class VideoMusicTransformer_V2(nn.Module):
         dev = self.Wout.weight.device
         if dev.type != "cuda":
             raise _lib.AmtError("VideoMusicTransformer_V2 runs on an MI355X only; video2music_amd has no CPU fallback")
-        sig = tuple((q.data_ptr(), q._version) for q in (self.Linear_chord.weight, self.embedding_root.weight,
-                                                           self.embedding_attr.weight, self.Linear_vis.weight))
+        srcs = [self.Linear_chord.weight, self.embedding_root.weight, self.embedding_attr.weight, self.Linear_vis.weight]
+        if self.chord_embed:
+            srcs.append(self.chord_embedding_model.weight)
+        if self._learned_pos:
+            srcs += [self.positional_embedding.weight, self.positional_embedding_video.weight]
+        sig = tuple((q.data_ptr(), q._version) for q in srcs)
         if sig != self._derived_sig:
             d, F = self.d_model, self.total_vf_dim
             Wc = self.Linear_chord.weight.detach()
             Wc_main = Wc[:, :d].contiguous()
             self._wkey = Wc[:, d].contiguous()
-            self._PR = ops.linear(self.embedding_root.weight.detach().contiguous(), Wc_main)
-            self._PA = ops.linear(self.embedding_attr.weight.detach().contiguous(), Wc_main)
+            if self.chord_embed:
+                # x = chord_embedding_model(x) (:431-432): one table indexed by the chord id; the attr slot adds a zero row
+                self._PR = ops.linear(self.chord_embedding_model.weight.detach().contiguous(), Wc_main)
+                self._PA = torch.zeros(CHORD_ATTR_SIZE, d, device=dev)
+            else:
+                self._PR = ops.linear(self.embedding_root.weight.detach().contiguous(), Wc_main)
+                self._PA = ops.linear(self.embedding_attr.weight.detach().contiguous(), Wc_main)
             self._Fpad = (F + 31) // 32 * 32
             Wv = torch.zeros(d, self._Fpad, device=dev)
             Wv[:, :F] = self.Linear_vis.weight.detach()
             self._Wvis_pad = Wv
-            self._zero_pe = torch.zeros(self.max_seq_chord, d, device=dev)
+            # positional rows added to the chord embedding: the learned table of version '2.0' (:497-503) or none
+            self._pe_chord = (self.positional_embedding.weight.detach().contiguous() if self._learned_pos
+                              else torch.zeros(self._max_dec, d, device=dev))
             self._derived_sig = sig
 
     def _attention(self, xq, xkv, a, Lq, Lk, B, causal, resid):
@@ -505,8 +547,9 @@ class VideoMusicTransformer_V2(nn.Module):
         q = ops.linear(xq, W[:E], b[:E])
         k = ops.linear(xkv, W[E:2 * E], b[E:2 * E])
         v = ops.linear(xkv, W[2 * E:], b[2 * E:])
-        q = ops.rope(q.view(H, Lq, B, hd), self._rope_cache).view(Lq * B, E)       # raw (H, L, B, hd) view (:1041-1053)
-        k = ops.rope(k.view(H, Lk, B, hd), self._rope_cache).view(Lk * B, E)
+        if self._rope_cache is not None:
+            q = ops.rope(q.view(H, Lq, B, hd), self._rope_cache).view(Lq * B, E)       # raw (H, L, B, hd) view (:1041-1053)
+            k = ops.rope(k.view(H, Lk, B, hd), self._rope_cache).view(Lk * B, E)
         o = torch.empty(Lq * B, E, device=xq.device, dtype=torch.float32)
         st = (E, hd, B * E) * 4                                                     # (L, B, E) buffers: b, h, l strides
         ops.attention(q, k, v, st, B, H, Lq, Lk, hd, causal, 1.0 / math.sqrt(hd), o)
@@ -533,9 +576,13 @@ class VideoMusicTransformer_V2(nn.Module):
         if motion.dim() == 2:
             motion = motion.unsqueeze(-1).contiguous()
         B, S, d = sem.shape[0], sem.shape[1], self.d_model
-        if S > self.max_seq_video:
-            raise ValueError(f"video longer than the RoPE cache ({self.max_seq_video}), like in the reference")
-        vf = ops.linear(ops.concat_features(sem, scene, motion, emotion, self._Fpad), self._Wvis_pad, self.Linear_vis.bias.detach())
+        if S > self.max_seq_video and (self._use_rope or self._learned_pos):
+            raise ValueError(f"video longer than the positional table ({self.max_seq_video}), like in the reference")
+        pos_rows = None
+        if self._learned_pos:                                   # vf += positional_embedding_video(arange(S)) (:499-501)
+            pos_rows = self.positional_embedding_video.weight.detach()[:S].unsqueeze(0).expand(B, S, d).contiguous().view(B * S, d)
+        vf = ops.linear(ops.concat_features(sem, scene, motion, emotion, self._Fpad), self._Wvis_pad, self.Linear_vis.bias.detach(),
+                        resid=pos_rows)
         src = vf.view(B, S, d).permute(1, 0, 2).contiguous().view(S * B, d)
         for lyr in self.transformer.encoder.layers:
             src = self._ln(self._attention(src, src, lyr.self_attn, S, S, B, False, src), lyr.norm1)
@@ -547,12 +594,12 @@ class VideoMusicTransformer_V2(nn.Module):
         from .. import ops
         dev = self.Wout.weight.device
         L, d = x_root.shape[1], self.d_model
-        if L > self.max_seq_video:
-            raise ValueError(f"chord sequence longer than the RoPE cache ({self.max_seq_video}), like in the reference")
+        if L > self._max_dec:
+            raise ValueError(f"chord sequence longer than the positional table ({self._max_dec}), like in the reference")
         key = feature_key.to(device=dev, dtype=torch.float32).reshape(-1)
         key = key.expand(B).contiguous() if key.numel() == 1 else key.contiguous()
         xf = ops.chord_embed(x_root.to(dev).long().contiguous(), x_attr.to(dev).long().contiguous(), key, self._PR, self._PA,
-                             self._wkey, self.Linear_chord.bias.detach(), self._zero_pe)
+                             self._wkey, self.Linear_chord.bias.detach(), self._pe_chord)
         t = xf.view(B, L, d).permute(1, 0, 2).contiguous().view(L * B, d)
         for lyr in self.transformer.decoder.layers:
             t = self._ln(self._attention(t, t, lyr.self_attn, L, L, B, True, t), lyr.norm1)
@@ -577,10 +624,11 @@ class VideoMusicTransformer_V2(nn.Module):
             a = lyr.cross_attn
             W, b = a.in_proj_weight.detach(), a.in_proj_bias.detach()
             k = ops.linear(memory, W[E:2 * E], b[E:2 * E])
-            k = ops.rope(k.view(H, S, 1, hd), self._rope_cache).view(S, E)
+            if self._rope_cache is not None:
+                k = ops.rope(k.view(H, S, 1, hd), self._rope_cache).view(S, E)
             v = ops.linear(memory, W[2 * E:], b[2 * E:])
             st["cross"].append((k, v))
-            st["self"].append((torch.empty(self.max_seq_video, E, device=dev), torch.empty(self.max_seq_video, E, device=dev)))
+            st["self"].append((torch.empty(self._max_dec, E, device=dev), torch.empty(self._max_dec, E, device=dev)))
         # pointer table of amt_v2_step (include/amt_hip.h); `keep` holds every tensor the table points into
         keep, ptrs = [], []
 
@@ -614,12 +662,12 @@ class VideoMusicTransformer_V2(nn.Module):
 
         for t in (self._PR, self._PA, self._wkey, self.Linear_chord.bias, self._rope_cache, self.transformer.decoder.norm.weight,
                   self.transformer.decoder.norm.bias, packed(self.Wout.weight), self.Wout.bias,
-                  torch.tensor([0, 1], device=dev, dtype=torch.int32)):
+                  torch.tensor([0, 1], device=dev, dtype=torch.int32), self._pe_chord if self._learned_pos else None):
             add(t)
         from .moe import GLUExpert, _stack
         dff = None
         # the one-call step streams K/V with the decode-attention kernel: head-major caches (H, rows, hd)
-        st["self_hm"] = [(torch.empty(H, self.max_seq_video, hd, device=dev), torch.empty(H, self.max_seq_video, hd, device=dev))
+        st["self_hm"] = [(torch.empty(H, self._max_dec, hd, device=dev), torch.empty(H, self._max_dec, hd, device=dev))
                          for _ in st["self"]]
         st["cross_hm"] = [(k.view(S, H, hd).permute(1, 0, 2).contiguous(), v.view(S, H, hd).permute(1, 0, 2).contiguous())
                           for k, v in st["cross"]]
@@ -663,7 +711,7 @@ class VideoMusicTransformer_V2(nn.Module):
         """`_decode_step` issued by one library call (amt_v2_step): logits (159,) for input position t.  With `state`
         (int32 device tensor {position, root, attr}) the step reads those from device memory and increments the position."""
         _lib.call("amt_v2_step", st["tab"], self.nlayers, self.nhead, self.d_model, st["dff"], self.n_experts, st["S"],
-                  self.max_seq_video, int(t), int(root), int(attr), float(key), _lib.ptr(state), _lib.ptr(st["logits"]),
+                  self._max_dec, int(t), int(root), int(attr), float(key), _lib.ptr(state), _lib.ptr(st["logits"]),
                   _lib.ptr(st["ws"]), _lib.stream_ptr())
         return st["logits"]
 
@@ -688,19 +736,26 @@ class VideoMusicTransformer_V2(nn.Module):
         hd = E // H
         scale = 1.0 / math.sqrt(hd)
         strides = (E, hd, E) * 4
-        x = ops.chord_embed(root_t, attr_t, key, self._PR, self._PA, self._wkey, self.Linear_chord.bias.detach(), self._zero_pe)
+        x = ops.chord_embed(root_t, attr_t, key, self._PR, self._PA, self._wkey, self.Linear_chord.bias.detach(), self._pe_chord[t:t + 1])
+        rope = self._rope_cache
         for lyr, (kc, vc), (kx, vx) in zip(self.transformer.decoder.layers, st["self"], st["cross"]):
             a = lyr.self_attn
             qkv = ops.linear(x, a.in_proj_weight.detach(), a.in_proj_bias.detach())                     # (1, 3E)
-            q = ops.rope(qkv[:, :E].view(1, 1, 1, E), self._rope_cache, pos=t).view(1, E)
-            ops.rope(qkv[:, E:2 * E].view(1, 1, 1, E), self._rope_cache, pos=t, out=kc[t:t + 1].view(1, 1, 1, E))
+            if rope is not None:
+                q = ops.rope(qkv[:, :E].view(1, 1, 1, E), rope, pos=t).view(1, E)
+                ops.rope(qkv[:, E:2 * E].view(1, 1, 1, E), rope, pos=t, out=kc[t:t + 1].view(1, 1, 1, E))
+            else:
+                q = qkv[:, :E].contiguous()
+                kc[t:t + 1].copy_(qkv[:, E:2 * E])
             vc[t:t + 1].copy_(qkv[:, 2 * E:])
             o = torch.empty(1, E, device=x.device, dtype=torch.float32)
             ops.attention(q, kc, vc, strides, 1, H, 1, t + 1, hd, False, scale, o)
             x = self._ln(ops.linear(o, a.out_proj.weight.detach(), a.out_proj.bias.detach(), resid=x), lyr.norm1)
             a = lyr.cross_attn
             W, b = a.in_proj_weight.detach(), a.in_proj_bias.detach()
-            q = ops.rope(ops.linear(x, W[:E], b[:E]).view(1, 1, 1, E), self._rope_cache, pos=t).view(1, E)
+            q = ops.linear(x, W[:E], b[:E])
+            if rope is not None:
+                q = ops.rope(q.view(1, 1, 1, E), rope, pos=t).view(1, E)
             ops.attention(q, kx, vx, strides, 1, H, 1, st["S"], hd, False, scale, o)
             x = self._ln(ops.linear(o, a.out_proj.weight.detach(), a.out_proj.bias.detach(), resid=x), lyr.norm2)
             x = self._ln(self._ff(x, lyr.ff, 1, 1), lyr.norm3, resid=x)
@@ -713,6 +768,8 @@ class VideoMusicTransformer_V2(nn.Module):
             raise NotImplementedError("forward(mask=False) is not used by any reference caller")
         memory, B, S = self._encode_memory(feature_semantic_list, feature_scene_offset, feature_motion, feature_emotion)
         assert x_root.shape[0] == B, f"{x_root.shape[0]} chord sequences but {B} clips of video features"
+        if self.chord_embed:                     # the chord ids themselves index the frozen table (:431-432)
+            x_root, x_attr = x, torch.zeros_like(x)
         return self._decode(x_root, x_attr, feature_key, memory, B, S)
 
     def generate(self, feature_semantic_list=[], feature_key=None, feature_scene_offset=None, feature_motion=None,
@@ -737,13 +794,15 @@ class VideoMusicTransformer_V2(nn.Module):
         gen_attr = torch.full((1, T), CHORD_ATTR_PAD, dtype=torch.long)
         P = len(primer)
         gen[0, :P], gen_root[0, :P], gen_attr[0, :P] = primer.cpu().long(), primer_root.cpu().long(), primer_attr.cpu().long()
+        if self.chord_embed:                     # the model input is the chord id (gen_seq, :547-548); the attr slot stays 0
+            gen_root[0, :P], gen_attr[0, :] = gen[0, :P], 0
         cur = P
         # the encoder output does not depend on the chords: it is computed once instead of every step (the reference
         # recomputes the identical tensor inside each forward, :547-548)
         memory, B, S = self._encode_memory(feature_semantic_list, feature_scene_offset, feature_motion, feature_emotion)
         assert B == 1, "generate takes one clip, like the reference (:528-530)"
-        if T > self.max_seq_video:
-            raise ValueError(f"chord sequence longer than the RoPE cache ({self.max_seq_video}), like in the reference")
+        if T > self._max_dec:
+            raise ValueError(f"chord sequence longer than the positional table ({self._max_dec}), like in the reference")
         if use_cache:
             key_val = float(feature_key.reshape(-1)[0])
             st = self._cache_init(memory, S)
@@ -770,6 +829,8 @@ class VideoMusicTransformer_V2(nn.Module):
             probs = torch.softmax(row / temperature, dim=-1)[:CHORD_END]
             if beam == 1:
                 gen[0, cur] = int(torch.topk(probs, 1)[1][0])
+                if self.chord_embed:        # the ids are the model input here, so the top-1 choice does feed back
+                    gen_root[0, cur] = gen[0, cur]
             else:
                 if max_conseq_N == 0:
                     probs[0] = 0.0
@@ -780,6 +841,6 @@ class VideoMusicTransformer_V2(nn.Module):
                 else:
                     tok = int(torch.distributions.categorical.Categorical(probs=probs).sample())
                 gen[0, cur] = tok
-                gen_root[0, cur], gen_attr[0, cur] = chord_to_root_attr(tok)
+                gen_root[0, cur], gen_attr[0, cur] = (tok, 0) if self.chord_embed else chord_to_root_attr(tok)
             cur += 1
         return gen[:, :cur].to(dev)
