@@ -131,6 +131,9 @@ int32_t amt_layernorm_fwd(const float* x, const float* resid, const float* w, co
                           int32_t rows, int32_t dim, float eps, void* stream);
 /* RMSNorm.forward (custom_transformer.py:38-45); w may be null. */
 int32_t amt_rmsnorm_fwd(const float* x, const float* w, float* y, int32_t rows, int32_t dim, float eps, void* stream);
+/* RMSNorm(x + resid): the post-norm residual form of the custom layers (custom_transformer.py:1233-1240); resid may be null. */
+int32_t amt_rmsnorm_resid_fwd(const float* x, const float* resid, const float* w, float* y, int32_t rows, int32_t dim,
+                              float eps, void* stream);
 /* RotaryPositionalEmbeddings.forward (rotate_operation.py:111-165), input_pos=None: x is
  * (n0, seq, n2, hd); cache is the module's (max_seq, cache_half, 2) buffer. */
 int32_t amt_rope_fwd(const float* x, const float* cache, float* y, int32_t n0, int32_t seq, int32_t n2, int32_t hd,
@@ -229,6 +232,8 @@ int32_t amt_moe_combine_fwd(const float* y_rows, const int32_t* slot_pos, const 
  * norm1 w, b, packed cross in_proj rows 0:E, its bias, packed out_proj, b, norm2 w, b, norm3 w, b, self K cache, V cache
  * (head-major: H, max_seq, hd), cross K (roped), V (head-major: H, S, hd), router w (null = plain GLU layer), router b, packed linear1, b, packed gate, b,
  * packed linear2, b (per expert, stacked, for a MoE layer), shared expert's six tensors (packed weights) or null).
+ * A null norm bias selects RMSNorm (eps 1e-6) for that norm; a null linear1 selects Linear -> SiLU -> Linear experts
+ * (h = silu(gate-slot projection)): the V1 family (video_music_transformer.py:22-314).
  * ws: amt_v2_step_ws_floats(E, dff, n_exp) floats.  E, dff multiples of 64, at most 1536.
  * state_dev (optional): int32 {position, root, attr} in device memory; when given, t / root / attr are read there and the
  * position is incremented at the end of the step, so that one captured graph of the step can be replayed for every token. */

@@ -69,6 +69,21 @@ def test_v2_state_dict_matches_reference_key_set():
     assert v20.positional_embedding.weight.shape == (64, CFG_V2["d_model"]) and v20._rope_cache is None
 
 
+def test_v1_state_dict_matches_reference_key_counts(golden):
+    """Key counts of the reference's V1 class for every layer plan (recorded by oracle/make_goldens_v1.py); names and shapes
+    are exercised by the GPU parity tests, which load procedural weights by name."""
+    from video2music_amd.model.video_music_transformer import VideoMusicTransformer_V1
+    g = golden("g_v1.npz")
+    cfg = dict(n_layers=4, num_heads=4, d_model=128, dim_feedforward=256, max_sequence_chord=300, total_vf_dim=1287)
+    for tag, version, rms in (("v10", "1.0", False), ("v11", "1.1", False), ("v12", "1.2", False), ("v13", "1.3", False),
+                              ("v133", "1.3.3", False), ("v134", "1.3.4", False), ("v11rms", "1.1", True)):
+        m = VideoMusicTransformer_V1(version_name=version, rms_norm=rms, **cfg)
+        assert len(m.state_dict()) == int(g[f"{tag}_n_keys"]), tag
+    sd = VideoMusicTransformer_V1(version_name="1.0", **cfg).state_dict()
+    assert sd["transformer.decoder.layers.0.ff.experts.5.3.weight"].shape == (128, 256)      # Linear(d,2d) -> SiLU -> Linear(2d,d)
+    assert "transformer.decoder.layers.0.ff.shared_expert.0.weight" not in sd                 # '1.0': MoELayer, no shared expert
+
+
 def test_unsupported_constructor_options_raise():
     with pytest.raises(NotImplementedError):
         VideoMusicTransformer(total_vf_dim=1287, rpr=False)

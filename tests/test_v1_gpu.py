@@ -1,0 +1,80 @@
+"""VideoMusicTransformer_V1 family on the HIP operator kernels vs goldens produced by the
+reference's own V1 class (oracle/make_goldens_v1.py): every layer plan its version strings select."""
+import numpy as np
+import pytest
+import torch
+
+from video2music_amd import synthetic
+from video2music_amd.model.video_music_transformer import VideoMusicTransformer_V1
+from tests.helpers import feats_t
+
+pytestmark = pytest.mark.gpu
+CFG = dict(n_layers=4, num_heads=4, d_model=128, dim_feedforward=256, max_sequence_chord=300, total_vf_dim=synthetic.total_vf_dim(1))
+CASES = [("v10", "1.0", False), ("v11", "1.1", False), ("v12", "1.2", False), ("v13", "1.3", False),
+         ("v133", "1.3.3", False), ("v134", "1.3.4", False), ("v11rms", "1.1", True)]
+
+
+def build(version, rms=False, **over):
+    m = VideoMusicTransformer_V1(version_name=version, rms_norm=rms, **dict(CFG, **over)).eval()
+    shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=0).items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected
+    return m.cuda()
+
+
+def gen_kw(f, T=20):
+    return dict(feature_semantic_list=f["semantic"], feature_key=f["key"][0], feature_scene_offset=f["scene_offset"],
+                feature_motion=f["motion"], feature_emotion=f["emotion"], primer=torch.tensor([1]), primer_root=torch.tensor([1]),
+                primer_attr=torch.tensor([0]), target_seq_length=T)
+
+
+@pytest.mark.parametrize("tag,version,rms", CASES)
+def test_v1_vs_reference_golden(golden, tag, version, rms):
+    g = golden("g_v1.npz")
+    m = build(version, rms)
+    assert len(m.state_dict()) == int(g[f"{tag}_n_keys"])
+    assert (m._rope_cache is not None) == (version == "1.2")            # '1.2' in '1.2.3': the reference's substring test
+    key = np.array([[0.0], [1.0], [0.0]], dtype=np.float32)
+    feats = synthetic.synthetic_features(3, seed=1234)
+    f = {k: v.cuda() for k, v in feats_t(feats, slice(0, 2), key=key).items()}
+    root, attr = torch.from_numpy(g[f"{tag}_root"]), torch.from_numpy(g[f"{tag}_attr"])
+    with torch.no_grad():
+        y = m(root, root, attr, f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"])
+    err = np.abs(y.cpu().numpy() - g[f"{tag}_logits"]).max()
+    assert y.shape == (2, 12, 159) and err < 1e-3, (tag, err)
+    f = {k: v.cuda() for k, v in feats_t(feats, slice(0, 1), key=key).items()}
+    with torch.no_grad():
+        assert np.array_equal(m.generate(beam=1, **gen_kw(f)).cpu().numpy(), g[f"{tag}_g1"])
+        for graph in (True, False):
+            assert np.array_equal(m.generate(beam=0, sampler="argmax", use_graph=graph, **gen_kw(f)).cpu().numpy(), g[f"{tag}_g2"])
+        assert np.array_equal(m.generate(beam=0, sampler="argmax", use_cache=False, **gen_kw(f)).cpu().numpy(), g[f"{tag}_g2"])
+
+
+@pytest.mark.parametrize("version,over", [("1.3.3", dict(dim_feedforward=192)), ("1.0", dict(n_layers=2)), ("1.2", dict(max_sequence_chord=64))])
+def test_v1_cached_decode_equals_reforward(version, over):
+    """Shapes the goldens do not hold: GLU layers narrower than the SiLU experts ('1.3.3' with d_ff != 2d: the cached step
+    is then issued operator by operator), a 2-layer model, a positional table shorter than the RoPE cache."""
+    m = build(version, **over)
+    f = {k: v.cuda() for k, v in feats_t(synthetic.synthetic_features(1, seed=5)).items()}
+    T = 40
+    with torch.no_grad():
+        a = m.generate(beam=0, sampler="argmax", **gen_kw(f, T))
+        b = m.generate(beam=0, sampler="argmax", use_cache=False, **gen_kw(f, T))
+    assert torch.equal(a, b) and a.shape == (1, T)
+    if version == "1.2":
+        with pytest.raises(ValueError):
+            m.generate(beam=0, sampler="argmax", **gen_kw(f, 65))
+
+
+@pytest.mark.parametrize("version", ["1.3", "2.0"])
+def test_cli_runs_the_other_families(tmp_path, version):
+    """`python -m video2music_amd.generate -music_gen_version 1.x / 2.0`: the script picks the class by the version prefix
+    (generate.py:209-238); concurrent and one-at-a-time clips give the same ids."""
+    from video2music_amd import generate as G
+    base = ["--synthetic", "--n_clips", "3", "-n_layers", "4", "-num_heads", "4", "-d_model", "128", "-dim_feedforward", "256",
+            "-target_seq_length_chord", "24", "--sampler", "argmax", "-music_gen_version", version]
+    a = G.main(base + ["-output_dir", str(tmp_path / "a"), "--v2_streams", "1"]).cpu()
+    b = G.main(base + ["-output_dir", str(tmp_path / "b"), "--v2_streams", "2"]).cpu()
+    assert a.shape == (3, 24) and torch.equal(a, b)
+    assert (tmp_path / "a" / "clip000_chords.lab").exists()

@@ -48,6 +48,7 @@ SIGNATURES = {
     "amt_linear_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "amt_layernorm_fwd": [_P, _P, _P, _P, _P, _I, _I, _F, _P],
     "amt_rmsnorm_fwd": [_P, _P, _P, _I, _I, _F, _P],
+    "amt_rmsnorm_resid_fwd": [_P, _P, _P, _P, _I, _I, _F, _P],
     "amt_rope_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "amt_rpr_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "amt_cross_attn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -940,6 +940,12 @@ extern "C" int32_t amt_rmsnorm_fwd(const float* x, const float* w, float* y, int
     return amt_launch_rmsnorm(x, w, y, rows, dim, eps, (hipStream_t)stream);
 }
 
+extern "C" int32_t amt_rmsnorm_resid_fwd(const float* x, const float* resid, const float* w, float* y, int32_t rows, int32_t dim,
+                                         float eps, void* stream) {
+    AMT_CHECK_ARG(x && y, "amt_rmsnorm_resid_fwd: null pointer");
+    return amt_launch_rmsnorm(x, w, y, rows, dim, eps, (hipStream_t)stream, resid);
+}
+
 extern "C" int32_t amt_rope_fwd(const float* x, const float* cache, float* y, int32_t n0, int32_t seq, int32_t n2, int32_t hd,
                                 int32_t cache_half, void* stream) {
     AMT_CHECK_ARG(x && cache && y, "amt_rope_fwd: null pointer");

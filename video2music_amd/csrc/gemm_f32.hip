@@ -32,7 +32,8 @@ __device__ __forceinline__ void store_out(const GemmParams& p, int row, int col,
     }
     if (p.rowadd) v += p.rowadd[(size_t)(row % p.rowadd_period) * p.N + col];
     if (p.resid) v += p.resid[(size_t)row * p.ldr + col];
-    if (p.relu) v = fmaxf(v, 0.f);
+    if (p.relu == 1) v = fmaxf(v, 0.f);
+    else if (p.relu == 2) v = v / (1.0f + __expf(-v));
     if (p.sigmoid) v = 1.0f / (1.0f + __expf(-v));
     if (p.head_split == 0) {
         p.C[(size_t)row * p.ldc + col] = v;
@@ -195,7 +196,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             const float4 a = ld4(p.resid + (size_t)row * p.ldr + col);
             v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
         }
-        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (p.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        else if (p.relu == 2) {
+            v.x = v.x / (1.0f + __expf(-v.x)); v.y = v.y / (1.0f + __expf(-v.y));
+            v.z = v.z / (1.0f + __expf(-v.z)); v.w = v.w / (1.0f + __expf(-v.w));
+        }
         if (p.sigmoid) {
             v.x = 1.0f / (1.0f + __expf(-v.x)); v.y = 1.0f / (1.0f + __expf(-v.y));
             v.z = 1.0f / (1.0f + __expf(-v.z)); v.w = 1.0f / (1.0f + __expf(-v.w));
@@ -233,7 +238,7 @@ int32_t amt_launch_gemm(const GemmParams& p, hipStream_t stream) {
         small_mn = f ? atol(f) : 650000;
     }
     if (p.M <= small_m && (long)p.M * p.N <= small_mn && p.K % 64 == 0 && p.K <= 1536 && !p.head_split && !p.rowadd && !p.silu_mul &&
-        !p.sigmoid && !p.tile_group && !p.a_gather) {
+        !p.sigmoid && !p.tile_group && !p.a_gather && p.relu != 2) {
         DecodeGemmParams g{};
         g.B = p.M; g.eps = 1e-5f; g.x = p.A; g.ldx = p.lda; g.Wp = p.W; g.ldw = p.ldw; g.bias = p.bias; g.N = p.N; g.K = p.K;
         g.resid = p.resid; g.ldr = p.ldr; g.relu = p.relu; g.scale = p.scale; g.scale_cols = p.scale_cols; g.y = p.C; g.ldy = p.ldc;

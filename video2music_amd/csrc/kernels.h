@@ -12,7 +12,7 @@ struct GemmParams {
     const float* resid; int ldr;    // [M][N] residual added after bias/scale, or null
     const float* rowadd; int rowadd_period;   // [period][N] row-periodic addend (positional encoding), or null
     float scale; int scale_cols;    // columns [0,scale_cols) are multiplied by scale after the bias (q * hd^-0.5)
-    int relu;
+    int relu;                       // 1: v = max(v, 0); 2: v = silu(v)
     int sigmoid;                    // v = 1/(1+exp(-v)) last (classifier heads)
     // head-split store: row=b*seq+s, col=part*d+h*hd+c -> C[part*part_stride + ((b*heads+h)*seq_cap+s)*hd+c]
     int head_split, hs_seq, hs_seq_cap, hs_d, hs_hd, hs_heads;
@@ -37,7 +37,8 @@ int32_t amt_launch_gemm(const GemmParams& p, hipStream_t stream);
 int32_t amt_launch_layernorm(const float* x, const float* resid, const float* w, const float* b,
                              const float* w2, const float* b2, float* y, int rows, int dim, float eps,
                              hipStream_t stream, const float* post = nullptr);
-int32_t amt_launch_rmsnorm(const float* x, const float* w, float* y, int rows, int dim, float eps, hipStream_t stream);
+int32_t amt_launch_rmsnorm(const float* x, const float* w, float* y, int rows, int dim, float eps, hipStream_t stream,
+                           const float* resid = nullptr);
 // rotary embedding on interleaved pairs: x viewed as [n0][seq][n2][hd], cache [>=seq][cache_half][2];
 // reproduces the reference's view(-1, seq, 1, hd/2, 2)[:n0] reinterpretation of the cache
 int32_t amt_launch_rope(const float* x, const float* cache, float* y, int n0, int seq, int n2, int hd,

@@ -134,7 +134,7 @@ extern "C" int32_t amt_moe_fwd(const float* x, const float* gate_w, const float*
                                const float* sw1, const float* sb1, const float* swg, const float* sbg, const float* sw2, const float* sb2,
                                float* out, int32_t* idx_out, float* w_out, float* scratch,
                                int32_t n_tok, int32_t d, int32_t dff, int32_t n_exp, void* stream) {
-    AMT_CHECK_ARG(x && gate_w && w1 && wg && w2 && out && scratch, "amt_moe_fwd: null pointer");
+    AMT_CHECK_ARG(x && gate_w && wg && w2 && out && scratch, "amt_moe_fwd: null pointer");
     AMT_CHECK_ARG(n_tok > 0 && n_exp >= 2 && n_exp <= 64, "amt_moe_fwd: need 2 <= n_experts <= 64");
     AMT_CHECK_ARG(d % 32 == 0 && dff % 32 == 0, "amt_moe_fwd: d and d_ff must be multiples of 32");
     hipStream_t s = (hipStream_t)stream;
@@ -163,26 +163,33 @@ extern "C" int32_t amt_moe_fwd(const float* x, const float* gate_w, const float*
     AMT_LAUNCH_CHECK();
     int32_t rc;
     // gate branch: G = x_e . Wg[e]^T + bg[e]
-    GemmParams g = gemm_params(x, d, wg, d, G, dff, Mp, dff, d, bg);
+    // (w1 == null: the experts are Linear -> SiLU -> Linear, video_music_transformer.py:80-85: H = silu(G), one launch)
+    GemmParams g = gemm_params(x, d, wg, d, w1 ? G : Hh, dff, Mp, dff, d, bg);
     g.a_gather = perm; g.tile_group = tile_group; g.w_group_stride = (size_t)dff * d; g.bias_group_stride = dff;
+    g.relu = w1 ? 0 : 2;
     if ((rc = amt_launch_gemm(g, s))) return rc;
-    // up branch fused with the gate: H = (x_e . W1[e]^T + b1[e]) * silu(G)
-    GemmParams u = gemm_params(x, d, w1, d, Hh, dff, Mp, dff, d, b1);
-    u.a_gather = perm; u.tile_group = tile_group; u.w_group_stride = (size_t)dff * d; u.bias_group_stride = dff;
-    u.silu_mul = G; u.ld_silu = dff;
-    if ((rc = amt_launch_gemm(u, s))) return rc;
+    if (w1) {
+        // up branch fused with the gate: H = (x_e . W1[e]^T + b1[e]) * silu(G)
+        GemmParams u = gemm_params(x, d, w1, d, Hh, dff, Mp, dff, d, b1);
+        u.a_gather = perm; u.tile_group = tile_group; u.w_group_stride = (size_t)dff * d; u.bias_group_stride = dff;
+        u.silu_mul = G; u.ld_silu = dff;
+        if ((rc = amt_launch_gemm(u, s))) return rc;
+    }
     // down: Y = H . W2[e]^T + b2[e]
     GemmParams dn = gemm_params(Hh, dff, w2, dff, Y, d, Mp, d, dff, b2);
     dn.tile_group = tile_group; dn.w_group_stride = (size_t)d * dff; dn.bias_group_stride = d;
     if ((rc = amt_launch_gemm(dn, s))) return rc;
     const float* shared = nullptr;
-    if (sw1) {
-        AMT_CHECK_ARG(swg && sw2, "amt_moe_fwd: incomplete shared expert");
-        GemmParams a = gemm_params(x, d, swg, d, Gs, dff, n_tok, dff, d, sbg);
+    if (swg) {
+        AMT_CHECK_ARG(sw2 && (sw1 != nullptr) == (w1 != nullptr), "amt_moe_fwd: incomplete shared expert");
+        GemmParams a = gemm_params(x, d, swg, d, sw1 ? Gs : Hs, dff, n_tok, dff, d, sbg);
+        a.relu = sw1 ? 0 : 2;
         if ((rc = amt_launch_gemm(a, s))) return rc;
-        GemmParams b = gemm_params(x, d, sw1, d, Hs, dff, n_tok, dff, d, sb1);
-        b.silu_mul = Gs; b.ld_silu = dff;
-        if ((rc = amt_launch_gemm(b, s))) return rc;
+        if (sw1) {
+            GemmParams b = gemm_params(x, d, sw1, d, Hs, dff, n_tok, dff, d, sb1);
+            b.silu_mul = Gs; b.ld_silu = dff;
+            if ((rc = amt_launch_gemm(b, s))) return rc;
+        }
         GemmParams c = gemm_params(Hs, dff, sw2, dff, Ys, d, n_tok, d, dff, sb2);
         if ((rc = amt_launch_gemm(c, s))) return rc;
         shared = Ys;
@@ -206,16 +213,20 @@ extern "C" int32_t amt_moe_route_fwd(const float* x, const float* gate_w, const 
 extern "C" int32_t amt_glu_expert_fwd(const float* x, const float* w1, const float* b1, const float* wg, const float* bg,
                                       const float* w2, const float* b2, float* out, float* scratch,
                                       int32_t n, int32_t d, int32_t dff, void* stream) {
-    AMT_CHECK_ARG(x && w1 && wg && w2 && out && scratch, "amt_glu_expert_fwd: null pointer");
+    AMT_CHECK_ARG(x && wg && w2 && out && scratch, "amt_glu_expert_fwd: null pointer");
     AMT_CHECK_ARG(n > 0 && d % 32 == 0 && dff % 32 == 0, "amt_glu_expert_fwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
     float* G = scratch;                     // [n][dff] gate branch
     float* Hh = G + (size_t)n * dff;        // [n][dff] (x W1^T + b1) * silu(G)
     int32_t rc;
-    if ((rc = amt_launch_gemm(gemm_params(x, d, wg, d, G, dff, n, dff, d, bg), s))) return rc;
-    GemmParams u = gemm_params(x, d, w1, d, Hh, dff, n, dff, d, b1);
-    u.silu_mul = G; u.ld_silu = dff;
-    if ((rc = amt_launch_gemm(u, s))) return rc;
+    GemmParams g = gemm_params(x, d, wg, d, w1 ? G : Hh, dff, n, dff, d, bg);
+    g.relu = w1 ? 0 : 2;                    // w1 == null: Linear -> SiLU -> Linear expert, H = silu(x Wg^T + bg)
+    if ((rc = amt_launch_gemm(g, s))) return rc;
+    if (w1) {
+        GemmParams u = gemm_params(x, d, w1, d, Hh, dff, n, dff, d, b1);
+        u.silu_mul = G; u.ld_silu = dff;
+        if ((rc = amt_launch_gemm(u, s))) return rc;
+    }
     return amt_launch_gemm(gemm_params(Hh, dff, w2, dff, out, d, n, d, dff, b2), s);
 }
 

@@ -170,9 +170,10 @@ int32_t amt_launch_layernorm(const float* x, const float* resid, const float* w,
     return 0;
 }
 
-int32_t amt_launch_rmsnorm(const float* x, const float* w, float* y, int rows, int dim, float eps, hipStream_t stream) {
+int32_t amt_launch_rmsnorm(const float* x, const float* w, float* y, int rows, int dim, float eps, hipStream_t stream,
+                           const float* resid) {
     AMT_CHECK_ARG(rows > 0 && dim > 0 && dim % 4 == 0 && dim <= 64 * 4 * MAX_CHUNKS, "rmsnorm: bad shape rows=%d dim=%d", rows, dim);
-    hipLaunchKernelGGL(norm_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, nullptr, w, nullptr, nullptr, nullptr, y, rows, dim, eps, nullptr);
+    hipLaunchKernelGGL(norm_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, resid, w, nullptr, nullptr, nullptr, y, rows, dim, eps, nullptr);
     AMT_LAUNCH_CHECK();
     return 0;
 }

@@ -62,10 +62,11 @@ __global__ void rope_place_kernel(const float* __restrict__ x, const float* __re
 }
 
 // h = u * silu(g)   (GLUExpert.forward, moe.py:44-49)
+// (u == null: h = silu(g), the Linear -> SiLU -> Linear experts of the V1 family)
 __global__ void glu_mul_kernel(const float* __restrict__ u, const float* __restrict__ g, float* __restrict__ h, int n) {
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i < n) {
-        const float4 a = ld4(u + i), b = ld4(g + i);
+        const float4 a = u ? ld4(u + i) : make_float4(1.f, 1.f, 1.f, 1.f), b = ld4(g + i);
         float4 o;
         o.x = a.x * (b.x / (1.0f + __expf(-b.x))); o.y = a.y * (b.y / (1.0f + __expf(-b.y)));
         o.z = a.z * (b.z / (1.0f + __expf(-b.z))); o.w = a.w * (b.w / (1.0f + __expf(-b.w)));
@@ -97,6 +98,13 @@ int32_t lin(const float* x, const float* wp, const float* b, const float* resid,
     return amt_launch_decode_gemm(g, s);
 }
 
+// one row through a layer's norm: LayerNorm(x + resid) (eps 1e-5), or -- bias pointer null -- RMSNorm(x + resid) (eps 1e-6,
+// custom_transformer.py:27-45: the V1 family built with rms_norm=True)
+int32_t norm_one(const float* x, const float* resid, const float* w, const float* b, float* y, int E, hipStream_t s) {
+    if (b) return amt_launch_layernorm(x, resid, w, b, nullptr, nullptr, y, 1, E, 1e-5f, s);
+    return amt_launch_rmsnorm(x, w, y, 1, E, 1e-6f, s, resid);
+}
+
 // GLUExpert on one row: y = W2 ((W1 x + b1) * silu(Wg x + bg)) + b2 ; scratch 3*dff floats
 int32_t glu_one(const float* x, const float* w1, const float* b1, const float* wg, const float* bg, const float* w2, const float* b2,
                 float* y, float* scratch, int E, int dff, hipStream_t s, const int* sel = nullptr) {
@@ -104,8 +112,8 @@ int32_t glu_one(const float* x, const float* w1, const float* b1, const float* w
     const size_t sw = (size_t)dff * E;
     int32_t rc;
     if ((rc = lin(x, wg, bg, nullptr, g, dff, E, s, sel, sw, dff))) return rc;
-    if ((rc = lin(x, w1, b1, nullptr, u, dff, E, s, sel, sw, dff))) return rc;
-    hipLaunchKernelGGL(glu_mul_kernel, dim3(cdiv(dff, 1024)), dim3(256), 0, s, u, g, hh, dff);
+    if (w1 && (rc = lin(x, w1, b1, nullptr, u, dff, E, s, sel, sw, dff))) return rc;
+    hipLaunchKernelGGL(glu_mul_kernel, dim3(cdiv(dff, 1024)), dim3(256), 0, s, w1 ? u : nullptr, g, hh, dff);
     AMT_LAUNCH_CHECK();
     return lin(hh, w2, b2, nullptr, y, E, dff, s, sel, sw, E);
 }
@@ -158,13 +166,13 @@ extern "C" int32_t amt_v2_step(const void* const* tab, int32_t n_layers, int32_t
         if ((rc = place(qkv + 2 * E, nullptr, vc, 1.f, E, hd, max_seq, t, pos, 1, s))) return rc;
         if ((rc = attn_one(q, kc, vc, o, H, hd, max_seq, t + 1, pos, s))) return rc;
         if ((rc = lin(o, P(L_SAOW), P(L_SAOB), x, u, E, E, s))) return rc;
-        if ((rc = amt_launch_layernorm(u, nullptr, P(L_N1W), P(L_N1B), nullptr, nullptr, x, 1, E, 1e-5f, s))) return rc;
+        if ((rc = norm_one(u, nullptr, P(L_N1W), P(L_N1B), x, E, s))) return rc;
         // cross-attention over the clip's (roped) video keys, head-major [H][S][hd]
         if ((rc = lin(x, P(L_CAW), P(L_CAB), nullptr, qkv, E, E, s))) return rc;
         if ((rc = place(qkv, rope_row, q, qscale, E, hd, 0, 0, pos, 0, s))) return rc;
         if ((rc = attn_one(q, P(L_KX), P(L_VX), o, H, hd, S, S, nullptr, s))) return rc;
         if ((rc = lin(o, P(L_CAOW), P(L_CAOB), x, u, E, E, s))) return rc;
-        if ((rc = amt_launch_layernorm(u, nullptr, P(L_N2W), P(L_N2B), nullptr, nullptr, x, 1, E, 1e-5f, s))) return rc;
+        if ((rc = norm_one(u, nullptr, P(L_N2W), P(L_N2B), x, E, s))) return rc;
         // feed-forward: GLU expert (shallow layers) or shared mixture of experts (router, the two chosen experts read
         // their weights through the device-side index, shared expert, weighted sum in expert-index order)
         if (!L[L_GATEW]) {
@@ -174,16 +182,16 @@ extern "C" int32_t amt_v2_step(const void* const* tab, int32_t n_layers, int32_t
             for (int slot = 0; slot < 2; ++slot)
                 if ((rc = glu_one(x, P(L_W1), P(L_B1), P(L_WG), P(L_BG), P(L_W2), P(L_B2), Y2 + (size_t)slot * E, ffs, E, dff, s, moe_idx + slot))) return rc;
             const float* shared = nullptr;
-            if (L[L_SW1]) {
+            if (L[L_SWG]) {
                 if ((rc = glu_one(x, P(L_SW1), P(L_SB1), P(L_SWG), P(L_SBG), P(L_SW2), P(L_SB2), ysh, ffs, E, dff, s))) return rc;
                 shared = ysh;
             }
             if ((rc = amt_moe_combine_fwd(Y2, (const int32_t*)tab[G_SLOT01], moe_idx, moe_w, shared, 0.5f, y, 1, E, s))) return rc;
         }
-        if ((rc = amt_launch_layernorm(y, x, P(L_N3W), P(L_N3B), nullptr, nullptr, u, 1, E, 1e-5f, s))) return rc;
+        if ((rc = norm_one(y, x, P(L_N3W), P(L_N3B), u, E, s))) return rc;
         float* tmp = x; x = u; u = tmp;
     }
-    if ((rc = amt_launch_layernorm(x, nullptr, G(G_FNW), G(G_FNB), nullptr, nullptr, y, 1, E, 1e-5f, s))) return rc;
+    if ((rc = norm_one(x, nullptr, G(G_FNW), G(G_FNB), y, E, s))) return rc;
     if ((rc = lin(y, G(G_WOUT), G(G_BOUT), nullptr, logits_out, 159, E, s))) return rc;
     if (pos) { hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, s, (int*)state_dev); AMT_LAUNCH_CHECK(); }
     return 0;

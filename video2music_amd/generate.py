@@ -18,7 +18,7 @@ import torch
 
 from . import dist as vdist
 from . import synthetic
-from .model.video_music_transformer import VideoMusicTransformer, VideoMusicTransformer_V2
+from .model.video_music_transformer import VideoMusicTransformer, VideoMusicTransformer_V1, VideoMusicTransformer_V2
 from .utilities import constants as C
 from .utilities.argument_generate_funcs import parse_generate_args
 from .utilities.device import get_device
@@ -65,9 +65,9 @@ def main(argv=None):
     args = parse_generate_args(argv)[0]
     if args.music_gen_version in ("None", "none", ""):
         args.music_gen_version = None
-    if args.music_gen_version is not None and not args.music_gen_version.startswith("2."):
-        raise SystemExit("built: music_gen_version None (base AMT) and the '2.x' family (VideoMusicTransformer_V2: 2.0, 2.1, 2.2); "
-                         "V1 / V3 are SURVEY.md §8 row f1")
+    if args.music_gen_version is not None and not args.music_gen_version.startswith(("1.", "2.")):
+        raise SystemExit("built: music_gen_version None (base AMT), the '1.x' family (VideoMusicTransformer_V1) and the '2.x' family "
+                         "(VideoMusicTransformer_V2: 2.0, 2.1, 2.2); V3 is SURVEY.md §8 row f1")
     if args.force_cpu:
         raise SystemExit("--force_cpu: video2music_amd has no CPU path (the CPU oracle lives in oracle/ for tests only)")
     rank, world, local = vdist.init()
@@ -96,7 +96,9 @@ def main(argv=None):
                   total_vf_dim=total_vf_dim_of(args, sem_dim=feats["semantic"].shape[-1]))     # generate.py:141-143: widths of the loaded features
     if args.music_gen_version is None:                 # generate.py:209-216
         model = VideoMusicTransformer(rpr=args.rpr, **common)
-    else:                                              # generate.py:225-230
+    elif args.music_gen_version.startswith("1."):      # generate.py:221-226
+        model = VideoMusicTransformer_V1(version_name=args.music_gen_version, rms_norm=args.rms_norm, **common)
+    else:                                              # generate.py:227-232
         model = VideoMusicTransformer_V2(version_name=args.music_gen_version, rms_norm=args.rms_norm, **common)
     if args.synthetic or args.synthetic_weights:
         shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]

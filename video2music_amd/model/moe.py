@@ -75,8 +75,40 @@ class GLUExpert(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
 
+class SiLUExpert(nn.Sequential):
+    """The other expert of the V1 family (video_music_transformer.py:80-85): ``nn.Sequential(Linear(d, d_ff), SiLU, Dropout,
+    Linear(d_ff, d))`` -- state_dict keys ``0.weight, 0.bias, 3.weight, 3.bias``."""
+
+    def __init__(self, d_model, d_ff, dropout=0.1):
+        super().__init__(nn.Linear(d_model, d_ff), nn.SiLU(), nn.Dropout(dropout), nn.Linear(d_ff, d_model))
+
+
+def expert_parts(e):
+    """{slot: nn.Linear or None} of an expert in the library's terms: y = W2 ((W1 x + b1) * silu(Wg x + bg)) + b2, with
+    linear1 = None for a SiLUExpert (y = W2 silu(Wg x + bg) + b2: its first Linear sits in the gate slot)."""
+    if isinstance(e, SiLUExpert):
+        return {"linear1": None, "gate": e[0], "linear2": e[3]}
+    return {"linear1": e.linear1, "gate": e.gate, "linear2": e.linear2}
+
+
+def expert_tensors(e):
+    """(w1, b1, wg, bg, w2, b2) contiguous, None where the expert has no such tensor."""
+    q = expert_parts(e)
+    out = []
+    for name in ("linear1", "gate", "linear2"):
+        out += [None, None] if q[name] is None else [q[name].weight.detach().contiguous(), q[name].bias.detach().contiguous()]
+    return out
+
+
+def expert_dff(e):
+    return expert_parts(e)["gate"].out_features
+
+
 def _stack(mods, attr, field):
-    return torch.stack([getattr(getattr(m, attr), field).detach() for m in mods]).contiguous()
+    lins = [expert_parts(m)[attr] for m in mods]
+    if lins[0] is None:
+        return None
+    return torch.stack([getattr(l, field).detach() for l in lins]).contiguous()
 
 
 class _MoEBase(nn.Module):
@@ -93,7 +125,7 @@ class _MoEBase(nn.Module):
     def _run_ep(self, x):
         L, B, d = x.shape
         n_tok, n_exp = L * B, self.n_experts
-        dff = self.experts[0].linear1.out_features
+        dff = expert_dff(self.experts[0])
         xf = x.to(torch.float32).contiguous().view(n_tok, d)
         p, st = _lib.ptr, _lib.stream_ptr
         idx = torch.empty(n_tok, 2, device=x.device, dtype=torch.int32)
@@ -109,7 +141,7 @@ class _MoEBase(nn.Module):
             if rows.shape[0] == 0:
                 return out
             scratch = torch.empty(2 * rows.shape[0] * dff, device=rows.device, dtype=torch.float32)
-            t = [v.detach().contiguous() for v in (m.linear1.weight, m.linear1.bias, m.gate.weight, m.gate.bias, m.linear2.weight, m.linear2.bias)]
+            t = expert_tensors(m)
             _lib.call("amt_glu_expert_fwd", p(rows), *[p(v) for v in t], p(out), p(scratch), rows.shape[0], d, dff, st())
             return out
 
@@ -155,15 +187,13 @@ class _MoEBase(nn.Module):
             return self._run_ep(x)
         L, B, d = x.shape
         n_tok, n_exp = L * B, self.n_experts
-        dff = self.experts[0].linear1.out_features
+        dff = expert_dff(self.experts[0])
         xf = x.to(torch.float32).contiguous()
         p = _lib.ptr
         w1, b1, wg, bg, w2, b2 = self._stacked_expert_weights()
         sh = [None] * 6
         if self.shared:
-            e = self.shared_expert
-            sh = [t.detach().contiguous() for t in (e.linear1.weight, e.linear1.bias, e.gate.weight, e.gate.bias,
-                                                     e.linear2.weight, e.linear2.bias)]
+            sh = expert_tensors(self.shared_expert)
         out = torch.empty(n_tok, d, device=x.device, dtype=torch.float32)
         idx = torch.empty(n_tok, 2, device=x.device, dtype=torch.int32)
         wts = torch.empty(n_tok, 2, device=x.device, dtype=torch.float32)

@@ -87,10 +87,10 @@ class _DecoderLayerParams(nn.Module):
 
 
 class _Stack(nn.Module):
-    def __init__(self, layers, d_model):
+    def __init__(self, layers, d_model, norm=None):
         super().__init__()
         self.layers = nn.ModuleList(layers)
-        self.norm = nn.LayerNorm(d_model)
+        self.norm = nn.LayerNorm(d_model) if norm is None else norm(d_model)
 
 
 class _TransformerParams(nn.Module):
@@ -403,32 +403,26 @@ class VideoMusicTransformer(nn.Module):
 class _DecoderLayerV2(nn.Module):
     """Keys of custom_transformer.TransformerDecoderLayer (model/custom_transformer.py:1250-1292)."""
 
-    def __init__(self, d_model, head_dim, ff, cross):
+    def __init__(self, d_model, head_dim, ff, cross, norm=nn.LayerNorm):
         super().__init__()
         self.self_attn = _AttnParams(d_model, head_dim)
         if cross:
             self.cross_attn = _AttnParams(d_model, head_dim)
         self.ff = ff
-        self.norm1 = nn.LayerNorm(d_model)
-        self.norm2 = nn.LayerNorm(d_model)
+        self.norm1 = norm(d_model)
+        self.norm2 = norm(d_model)
         if cross:
-            self.norm3 = nn.LayerNorm(d_model)
+            self.norm3 = norm(d_model)
 
 
 class _TransformerParamsV2(nn.Module):
-    def __init__(self, d_model, nhead, n_layers, d_ff, dropout, n_experts, balancing):
+    """Both stacks of the V1 / V2 families: layer i's feed-forward is ``ff(i)``, norms are built by ``norm(d_model)``."""
+
+    def __init__(self, d_model, nhead, n_layers, ff, norm=nn.LayerNorm):
         super().__init__()
-        from .moe import GLUExpert, SharedMoELayer
         hd = d_model // nhead
-
-        def ff(i):
-            if i < 3:                                            # rate = 3 shallow layers (:409-414)
-                return GLUExpert(d_model, d_ff, dropout)
-            return SharedMoELayer(GLUExpert(d_model, d_ff, dropout), d_model, n_experts=n_experts, n_experts_per_token=2,
-                                  dropout=dropout, balancing=balancing)
-
-        self.encoder = _Stack([_DecoderLayerV2(d_model, hd, ff(i), cross=False) for i in range(n_layers)], d_model)
-        self.decoder = _Stack([_DecoderLayerV2(d_model, hd, ff(i), cross=True) for i in range(n_layers)], d_model)
+        self.encoder = _Stack([_DecoderLayerV2(d_model, hd, ff(i), cross=False, norm=norm) for i in range(n_layers)], d_model, norm)
+        self.decoder = _Stack([_DecoderLayerV2(d_model, hd, ff(i), cross=True, norm=norm) for i in range(n_layers)], d_model, norm)
         for q in self.parameters():
             if q.dim() > 1:
                 nn.init.xavier_uniform_(q)
@@ -483,7 +477,15 @@ class VideoMusicTransformer_V2(nn.Module):
         if self._learned_pos:
             self.positional_embedding = nn.Embedding(max_sequence_chord, d_model)
             self.positional_embedding_video = nn.Embedding(max_sequence_video, d_model)
-        self.transformer = _TransformerParamsV2(d_model, num_heads, n_layers, dim_feedforward, dropout, self.n_experts, balancing)
+        from .moe import GLUExpert, SharedMoELayer
+
+        def ff(i):
+            if i < 3:                                            # rate = 3 shallow layers (:409-414)
+                return GLUExpert(d_model, dim_feedforward, dropout)
+            return SharedMoELayer(GLUExpert(d_model, dim_feedforward, dropout), d_model, n_experts=self.n_experts,
+                                  n_experts_per_token=2, dropout=dropout, balancing=balancing)
+
+        self.transformer = _TransformerParamsV2(d_model, num_heads, n_layers, ff)
         self.Wout = nn.Linear(d_model, CHORD_SIZE)
         self.softmax = nn.Softmax(dim=-1)
         if self._use_rope:
@@ -557,13 +559,15 @@ class VideoMusicTransformer_V2(nn.Module):
 
     def _ff(self, x, ff, L, B):
         from .. import ops
-        from .moe import GLUExpert
-        if isinstance(ff, GLUExpert):
+        from .moe import GLUExpert, SiLUExpert
+        if isinstance(ff, (GLUExpert, SiLUExpert)):
             return ops.glu(x, ff)
         return ff(x.view(L, B, self.d_model)).reshape(L * B, self.d_model)
 
     def _ln(self, t, n, resid=None):
         from .. import ops
+        if not isinstance(n, nn.LayerNorm):                      # RMSNorm (the V1 family with rms_norm=True)
+            return ops.rmsnorm(t, n.weight.detach(), resid=resid, eps=n.eps)
         return ops.layernorm(t, n.weight.detach(), n.bias.detach(), resid=resid, eps=n.eps)
 
     def _encode_memory(self, feature_semantic_list, feature_scene_offset, feature_motion, feature_emotion):
@@ -654,18 +658,30 @@ class VideoMusicTransformer_V2(nn.Module):
             return cache[sig]
 
         def packed_experts(experts, name):
-            sig = tuple((getattr(e, name).weight.data_ptr(), getattr(e, name).weight._version) for e in experts) + (name,)
+            lins = [expert_parts(e)[name] for e in experts]
+            sig = tuple((l.weight.data_ptr(), l.weight._version) for l in lins) + (name,)
             cache = self.__dict__.setdefault("_pack_cache", {})
             if sig not in cache:
-                cache[sig] = torch.cat([packed(getattr(e, name).weight) for e in experts])
+                cache[sig] = torch.cat([packed(l.weight) for l in lins])
             return cache[sig]
 
+        def nb(n):          # a norm's bias; None (RMSNorm) selects the RMS form inside the step
+            return getattr(n, "bias", None)
+
         for t in (self._PR, self._PA, self._wkey, self.Linear_chord.bias, self._rope_cache, self.transformer.decoder.norm.weight,
-                  self.transformer.decoder.norm.bias, packed(self.Wout.weight), self.Wout.bias,
+                  nb(self.transformer.decoder.norm), packed(self.Wout.weight), self.Wout.bias,
                   torch.tensor([0, 1], device=dev, dtype=torch.int32), self._pe_chord if self._learned_pos else None):
             add(t)
-        from .moe import GLUExpert, _stack
-        dff = None
+        from .moe import GLUExpert, SiLUExpert, _stack, expert_dff, expert_parts
+        dff, widths = None, set()
+
+        def add_expert(e):
+            """linear1 w, b (None for a SiLUExpert), gate w, b, linear2 w, b -- packed weights."""
+            q = expert_parts(e)
+            for name in ("linear1", "gate", "linear2"):
+                add(None if q[name] is None else packed(q[name].weight))
+                add(None if q[name] is None else q[name].bias)
+
         # the one-call step streams K/V with the decode-attention kernel: head-major caches (H, rows, hd)
         st["self_hm"] = [(torch.empty(H, self._max_dec, hd, device=dev), torch.empty(H, self._max_dec, hd, device=dev))
                          for _ in st["self"]]
@@ -673,36 +689,41 @@ class VideoMusicTransformer_V2(nn.Module):
                           for k, v in st["cross"]]
         for lyr, (kc, vc), (kx, vx) in zip(self.transformer.decoder.layers, st["self_hm"], st["cross_hm"]):
             sa, ca = lyr.self_attn, lyr.cross_attn
-            for t in (packed(sa.in_proj_weight), sa.in_proj_bias, packed(sa.out_proj.weight), sa.out_proj.bias, lyr.norm1.weight, lyr.norm1.bias,
+            for t in (packed(sa.in_proj_weight), sa.in_proj_bias, packed(sa.out_proj.weight), sa.out_proj.bias, lyr.norm1.weight, nb(lyr.norm1),
                       packed(ca.in_proj_weight, rows=E), ca.in_proj_bias, packed(ca.out_proj.weight), ca.out_proj.bias, lyr.norm2.weight,
-                      lyr.norm2.bias, lyr.norm3.weight, lyr.norm3.bias, kc, vc, kx, vx):
+                      nb(lyr.norm2), lyr.norm3.weight, nb(lyr.norm3), kc, vc, kx, vx):
                 add(t)
             ff = lyr.ff
-            if isinstance(ff, GLUExpert):
-                dff = ff.linear1.out_features
-                for t in (None, None, packed(ff.linear1.weight), ff.linear1.bias, packed(ff.gate.weight), ff.gate.bias,
-                          packed(ff.linear2.weight), ff.linear2.bias):
-                    add(t)
+            if isinstance(ff, (GLUExpert, SiLUExpert)):
+                layer_dff = expert_dff(ff)
+                add(None), add(None)
+                add_expert(ff)
                 for _ in range(6):
                     add(None)
             else:
                 if ff.n_experts_per_token != 2 or getattr(ff, "expert_parallel", False):
                     raise NotImplementedError("the cached V2 step is built for local top-2 MoE layers")
-                dff = ff.experts[0].linear1.out_features
+                layer_dff = expert_dff(ff.experts[0])
                 add(ff.gate.weight), add(ff.gate.bias)
                 for name in ("linear1", "gate", "linear2"):
-                    add(packed_experts(ff.experts, name))
-                    add(_stack(ff.experts, name, "bias"))
-                e = ff.shared_expert if ff.shared else None
-                if e is None:
+                    if expert_parts(ff.experts[0])[name] is None:
+                        add(None), add(None)
+                    else:
+                        add(packed_experts(ff.experts, name))
+                        add(_stack(ff.experts, name, "bias"))
+                if ff.shared:
+                    add_expert(ff.shared_expert)
+                else:
                     for _ in range(6):
                         add(None)
-                else:
-                    for t in (packed(e.linear1.weight), e.linear1.bias, packed(e.gate.weight), e.gate.bias, packed(e.linear2.weight), e.linear2.bias):
-                        add(t)
+            widths.add(layer_dff)
+            dff = layer_dff
         st["tab"] = (C.c_void_p * len(ptrs))(*ptrs)
         st["keep"] = keep
         st["dff"] = dff
+        # amt_v2_step lays its scratch out for one feed-forward width; layers of different widths (V1 '1.3.3' / '1.3.4' with
+        # dim_feedforward != 2 d_model) take the same cached step issued operator by operator (`_decode_step`)
+        st["native"] = len(widths) == 1
         st["ws"] = torch.empty(_lib.call("amt_v2_step_ws_floats", E, dff, self.n_experts), device=dev, dtype=torch.float32)
         st["logits"] = torch.empty(CHORD_SIZE, device=dev, dtype=torch.float32)
         return st
@@ -762,6 +783,14 @@ class VideoMusicTransformer_V2(nn.Module):
         x = self._ln(x, self.transformer.decoder.norm)
         return ops.linear(x, self.Wout.weight.detach(), self.Wout.bias.detach())[0]
 
+    def _decode_step_ops(self, root, attr, key, t, st):
+        """`_decode_step` with the call shape of `_decode_step_native` (host ints in, logits left in st["logits"])."""
+        dev = st["logits"].device
+        r = torch.tensor([[int(root)]], device=dev, dtype=torch.long)
+        a = torch.tensor([[int(attr)]], device=dev, dtype=torch.long)
+        st["logits"].copy_(self._decode_step(r, a, torch.tensor([float(key)], device=dev), int(t), st))
+        return st["logits"]
+
     def forward(self, x, x_root, x_attr, feature_semantic_list, feature_key, feature_scene_offset, feature_motion,
                 feature_emotion, mask=True):
         if mask is not True:
@@ -806,17 +835,20 @@ class VideoMusicTransformer_V2(nn.Module):
         if use_cache:
             key_val = float(feature_key.reshape(-1)[0])
             st = self._cache_init(memory, S)
+            if not st["native"]:
+                use_graph = False
             if use_graph:
                 graph, state = self._step_graph(key_val, st, gen_root[0, 0], gen_attr[0, 0])      # position 0 done
             else:
-                self._decode_step_native(gen_root[0, 0], gen_attr[0, 0], key_val, 0, st)
+                one = self._decode_step_native if st["native"] else self._decode_step_ops
+                one(gen_root[0, 0], gen_attr[0, 0], key_val, 0, st)
 
             def step(t):
                 if use_graph:
                     state[1:] = torch.stack((gen_root[0, t], gen_attr[0, t])).to(torch.int32)
                     graph.replay()
                 else:
-                    self._decode_step_native(gen_root[0, t], gen_attr[0, t], key_val, t, st)
+                    one(gen_root[0, t], gen_attr[0, t], key_val, t, st)
             for t in range(1, P - 1):       # primer positions whose logits are not needed: fill the caches
                 step(t)
         while cur < T:
@@ -844,3 +876,75 @@ class VideoMusicTransformer_V2(nn.Module):
                 gen_root[0, cur], gen_attr[0, cur] = (tok, 0) if self.chord_embed else chord_to_root_attr(tok)
             cur += 1
         return gen[:, :cur].to(dev)
+
+
+# ==================================================================================================
+# VideoMusicTransformer_V1 (second widening): the same machinery with another layer plan
+# ==================================================================================================
+class VideoMusicTransformer_V1(VideoMusicTransformer_V2):
+    """Reference ``VideoMusicTransformer_V1`` (model/video_music_transformer.py:22-314), eval mode.  Learned positional
+    tables on both streams (:63-65,198-206); every layer's feed-forward a 6-expert top-2 mixture -- ``MoELayer`` for
+    '1.0', '1.1', '1.3.4', else ``SharedMoELayer`` -- over ``GLUExpert(d, d_ff)`` ('1.1', '1.3') or
+    ``Linear(d, 2d) -> SiLU -> Linear(2d, d)`` experts (:77-85); '1.3.3' / '1.3.4' put three plain GLU layers first
+    (:108-125); RoPE inside the attentions when ``version_name in '1.2.3'`` -- the reference's substring test (:86), so
+    '1.2' gets it too; ``rms_norm=True`` swaps every LayerNorm for RMSNorm (:69-72).  ``nn.MultiheadAttention`` and
+    ``CustomMultiheadAttention`` carry the same parameter names and compute the same attention without RoPE, so one
+    code path serves both.  forward / generate / the KV-cached decode step are inherited from the V2 class.
+    """
+
+    def __init__(self, version_name="1.1", n_layers=6, num_heads=8, d_model=512, dim_feedforward=1024, dropout=0.1,
+                 max_sequence_midi=2048, max_sequence_video=300, max_sequence_chord=300, total_vf_dim=0, rms_norm=False,
+                 scene_embed=False, chord_embed=False, dropTokenRate=0.0):
+        nn.Module.__init__(self)
+        if scene_embed or dropTokenRate != 0.0:
+            raise NotImplementedError("scene_embed / dropTokenRate (a random mask applied even in eval, :191-196) are outside this path")
+        from .custom_transformer import RMSNorm
+        from .moe import GLUExpert, MoELayer, SharedMoELayer, SiLUExpert
+        shallow = version_name in ("1.3.3", "1.3.4")
+        if shallow and n_layers < 3:
+            raise ValueError("the reference builds 3 shallow + (n_layers-3) deep layers")
+        self.nlayers, self.nhead, self.d_model, self.d_ff, self.dropout = n_layers, num_heads, d_model, dim_feedforward, dropout
+        self.max_seq_midi, self.max_seq_video, self.max_seq_chord = max_sequence_midi, max_sequence_video, max_sequence_chord
+        self.scene_embed, self.chord_embed, self.dropTokenRate, self.version_name = scene_embed, chord_embed, dropTokenRate, version_name
+        self.total_vf_dim = total_vf_dim
+        self.n_experts, self.n_experts_per_token = 6, 2
+        self._learned_pos = True
+        self._use_rope = version_name in "1.2.3"                     # substring test, as written at :86
+        if chord_embed:
+            self.chord_embedding_model = nn.Embedding(CHORD_SIZE, d_model)
+            self.chord_embedding_model.weight.requires_grad_(False)
+            self._register_load_state_dict_pre_hook(self._resize_chord_table)
+        self.embedding = nn.Embedding(CHORD_SIZE, d_model)
+        self.embedding_root = nn.Embedding(CHORD_ROOT_SIZE, d_model)
+        self.embedding_attr = nn.Embedding(CHORD_ATTR_SIZE, d_model)
+        self.Linear_vis = nn.Linear(total_vf_dim, d_model)
+        self.Linear_chord = nn.Linear(d_model + 1, d_model)
+        self.positional_embedding = nn.Embedding(max_sequence_chord, d_model)
+        self.positional_embedding_video = nn.Embedding(max_sequence_video, d_model)
+        self.condition_linear = nn.Linear(1, d_model)
+
+        def expert():
+            if version_name in ("1.1", "1.3"):
+                return GLUExpert(d_model, dim_feedforward, dropout)
+            return SiLUExpert(d_model, 2 * d_model, dropout)
+
+        def ff(i):
+            if shallow and i < 3:
+                return GLUExpert(d_model, dim_feedforward, dropout)
+            if version_name in ("1.0", "1.1", "1.3.4"):
+                return MoELayer(expert(), d_model, self.n_experts, self.n_experts_per_token, dropout)
+            return SharedMoELayer(expert(), d_model, n_experts=self.n_experts, n_experts_per_token=self.n_experts_per_token,
+                                  balancing=False, dropout=dropout)
+
+        self.transformer = _TransformerParamsV2(d_model, num_heads, n_layers, ff, norm=RMSNorm if rms_norm else nn.LayerNorm)
+        self.Wout = nn.Linear(d_model, CHORD_SIZE)
+        self.softmax = nn.Softmax(dim=-1)
+        if self._use_rope:
+            from .rotate_operation import RotaryPositionalEmbeddings
+            rope = RotaryPositionalEmbeddings(d_model, max_sequence_video)
+            self.register_buffer("_rope_cache", rope.cache.clone(), persistent=False)
+        else:
+            self._rope_cache = None
+        # the RoPE cache caps the chord sequence at max_sequence_video, the positional table at max_sequence_chord
+        self._max_dec = min(max_sequence_video, max_sequence_chord) if self._use_rope else max_sequence_chord
+        self._derived_sig = None

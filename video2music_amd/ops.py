@@ -33,6 +33,14 @@ def layernorm(x, w, b, resid=None, eps=1e-5):
     return y
 
 
+def rmsnorm(x, w, resid=None, eps=1e-6):
+    """RMSNorm(x (+ resid)) * w (custom_transformer.py:27-45)."""
+    rows, dim = x.shape
+    y = torch.empty_like(x)
+    _lib.call("amt_rmsnorm_resid_fwd", p(x), p(resid), p(w), p(y), rows, dim, float(eps), _st())
+    return y
+
+
 def rope(x, cache, pos=0, out=None):
     """x (n0, seq, n2, hd) contiguous, cache (>=pos+seq, cache_half, 2): RotaryPositionalEmbeddings.forward on the
     cache rows pos..pos+seq-1 (pos > 0: one decode position); `out` receives the result (same numel)."""
@@ -51,11 +59,12 @@ def attention(q, k, v, strides, B, H, Lq, Lk, hd, causal, q_scale, out):
 
 def glu(x, e):
     """GLUExpert.forward on rows x (n, d): W2((W1 x + b1) * silu(Wg x + bg)) + b2."""
+    from .model.moe import expert_dff, expert_tensors
     n, d = x.shape
-    dff = e.linear1.out_features
+    dff = expert_dff(e)
     out = torch.empty(n, d, device=x.device, dtype=torch.float32)
     scratch = torch.empty(2 * n * dff, device=x.device, dtype=torch.float32)
-    t = [t_.detach().contiguous() for t_ in (e.linear1.weight, e.linear1.bias, e.gate.weight, e.gate.bias, e.linear2.weight, e.linear2.bias)]
+    t = expert_tensors(e)           # a SiLUExpert has no linear1: y = W2 silu(W x + b) + b2
     _lib.call("amt_glu_expert_fwd", p(x), *[p(v) for v in t], p(out), p(scratch), n, d, dff, _st())
     return out
 
