@@ -131,6 +131,13 @@ int32_t amt_layernorm_fwd(const float* x, const float* resid, const float* w, co
                           int32_t rows, int32_t dim, float eps, void* stream);
 /* RMSNorm.forward (custom_transformer.py:38-45); w may be null. */
 int32_t amt_rmsnorm_fwd(const float* x, const float* w, float* y, int32_t rows, int32_t dim, float eps, void* stream);
+/* Tail of DifferentialMultiheadAttention (custom_transformer.py:818-826; VideoMusicTransformer_V3): with o1 / o2 the
+ * attention outputs of the even / odd heads of a pair over the same values, y = RMSNorm_hd(o1 - lambda_full * o2) * w *
+ * out_scale (out_scale = 1 - lambda_init), rows of hd <= 128 values. */
+int32_t amt_diff_subln_fwd(const float* o1, const float* o2, const float* w, float* y, int32_t rows, int32_t hd,
+                           float lambda_full, float out_scale, float eps, void* stream);
+/* y = a + b over n floats (n % 4 == 0): the residual add of the pre-norm layers (custom_transformer.py:1241-1249). */
+int32_t amt_add_fwd(const float* a, const float* b, float* y, int64_t n, void* stream);
 /* RMSNorm(x + resid): the post-norm residual form of the custom layers (custom_transformer.py:1233-1240); resid may be null. */
 int32_t amt_rmsnorm_resid_fwd(const float* x, const float* resid, const float* w, float* y, int32_t rows, int32_t dim,
                               float eps, void* stream);

@@ -84,6 +84,20 @@ def test_v1_state_dict_matches_reference_key_counts(golden):
     assert "transformer.decoder.layers.0.ff.shared_expert.0.weight" not in sd                 # '1.0': MoELayer, no shared expert
 
 
+def test_v3_state_dict_matches_reference_key_counts(golden):
+    from video2music_amd.model.video_music_transformer import VideoMusicTransformer_V3
+    g = golden("g_v3.npz")
+    cfg = dict(n_layers=4, num_heads=4, d_model=128, dim_feedforward=256, max_sequence_chord=300, total_vf_dim=1287)
+    for tag, version in (("v30", "3.0"), ("v31", "3.1"), ("v32", "3.2")):
+        m = VideoMusicTransformer_V3(version_name=version, **cfg)
+        assert len(m.state_dict()) == int(g[f"{tag}_n_keys"]), tag
+    sd = m.state_dict()
+    assert sd["transformer.decoder.layers.3.cross_attn.q_proj.weight"].shape == (256, 128)
+    assert sd["transformer.decoder.layers.3.self_attn.subln.weight"].shape == (32,) and sd["transformer.decoder.layers.3.ff.bias"].shape == (6, 1)
+    assert "transformer.decoder.layers.0.norm1.bias" not in sd               # RMSNorm
+    assert abs(m.transformer.decoder.layers[2].self_attn.lambda_init - (0.8 - 0.6 * np.exp(-0.6))) < 1e-12
+
+
 def test_unsupported_constructor_options_raise():
     with pytest.raises(NotImplementedError):
         VideoMusicTransformer(total_vf_dim=1287, rpr=False)

@@ -946,6 +946,17 @@ extern "C" int32_t amt_rmsnorm_resid_fwd(const float* x, const float* resid, con
     return amt_launch_rmsnorm(x, w, y, rows, dim, eps, (hipStream_t)stream, resid);
 }
 
+extern "C" int32_t amt_diff_subln_fwd(const float* o1, const float* o2, const float* w, float* y, int32_t rows, int32_t hd,
+                                      float lambda_full, float out_scale, float eps, void* stream) {
+    AMT_CHECK_ARG(o1 && o2 && w && y, "amt_diff_subln_fwd: null pointer");
+    return amt_launch_diff_subln(o1, o2, w, y, rows, hd, lambda_full, out_scale, eps, (hipStream_t)stream);
+}
+
+extern "C" int32_t amt_add_fwd(const float* a, const float* b, float* y, int64_t n, void* stream) {
+    AMT_CHECK_ARG(a && b && y, "amt_add_fwd: null pointer");
+    return amt_launch_add(a, b, y, (long)n, (hipStream_t)stream);
+}
+
 extern "C" int32_t amt_rope_fwd(const float* x, const float* cache, float* y, int32_t n0, int32_t seq, int32_t n2, int32_t hd,
                                 int32_t cache_half, void* stream) {
     AMT_CHECK_ARG(x && cache && y, "amt_rope_fwd: null pointer");

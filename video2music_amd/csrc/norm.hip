@@ -159,7 +159,55 @@ __global__ void chord_embed_kernel(const int64_t* __restrict__ root, const int64
     }
 }
 
+// Differential attention tail (custom_transformer.py:818-826): y = RMSNorm_hd(o1 - lambda * o2) * w * out_scale per (clip,
+// head, position) row of hd <= 128 values; one wavefront per row.
+__global__ void diff_subln_kernel(const float* __restrict__ o1, const float* __restrict__ o2, const float* __restrict__ w,
+                                  float* __restrict__ y, int rows, int hd, float lambda, float out_scale, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const size_t base = (size_t)row * hd;
+    float v[2], ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int c = lane + 64 * k;
+        v[k] = c < hd ? o1[base + c] - lambda * o2[base + c] : 0.f;
+        ss += v[k] * v[k];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float r = rsqrtf(ss / (float)hd + eps);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int c = lane + 64 * k;
+        if (c < hd) y[base + c] = v[k] * r * w[c] * out_scale;
+    }
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long n4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) {
+        const float4 u = ld4(a + 4 * i), v = ld4(b + 4 * i);
+        st4(y + 4 * i, make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w));
+    }
+}
+
 }  // namespace
+
+int32_t amt_launch_diff_subln(const float* o1, const float* o2, const float* w, float* y, int rows, int hd, float lambda,
+                              float out_scale, float eps, hipStream_t stream) {
+    AMT_CHECK_ARG(rows > 0 && hd > 0 && hd <= 128, "diff_subln: bad shape rows=%d hd=%d", rows, hd);
+    hipLaunchKernelGGL(diff_subln_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, o1, o2, w, y, rows, hd, lambda, out_scale, eps);
+    AMT_LAUNCH_CHECK();
+    return 0;
+}
+
+int32_t amt_launch_add(const float* a, const float* b, float* y, long n, hipStream_t stream) {
+    AMT_CHECK_ARG(n > 0 && n % 4 == 0, "add: element count must be a positive multiple of 4");
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, a, b, y, n / 4);
+    AMT_LAUNCH_CHECK();
+    return 0;
+}
 
 int32_t amt_launch_layernorm(const float* x, const float* resid, const float* w, const float* b,
                              const float* w2, const float* b2, float* y, int rows, int dim, float eps,

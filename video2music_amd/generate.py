@@ -18,7 +18,8 @@ import torch
 
 from . import dist as vdist
 from . import synthetic
-from .model.video_music_transformer import VideoMusicTransformer, VideoMusicTransformer_V1, VideoMusicTransformer_V2
+from .model.video_music_transformer import (VideoMusicTransformer, VideoMusicTransformer_V1, VideoMusicTransformer_V2,
+                                            VideoMusicTransformer_V3)
 from .utilities import constants as C
 from .utilities.argument_generate_funcs import parse_generate_args
 from .utilities.device import get_device
@@ -65,9 +66,8 @@ def main(argv=None):
     args = parse_generate_args(argv)[0]
     if args.music_gen_version in ("None", "none", ""):
         args.music_gen_version = None
-    if args.music_gen_version is not None and not args.music_gen_version.startswith(("1.", "2.")):
-        raise SystemExit("built: music_gen_version None (base AMT), the '1.x' family (VideoMusicTransformer_V1) and the '2.x' family "
-                         "(VideoMusicTransformer_V2: 2.0, 2.1, 2.2); V3 is SURVEY.md §8 row f1")
+    if args.music_gen_version is not None and not args.music_gen_version.startswith(("1.", "2.", "3.")):
+        raise SystemExit("music_gen_version must be None (base AMT) or start with '1.', '2.' or '3.' (generate.py:209-238)")
     if args.force_cpu:
         raise SystemExit("--force_cpu: video2music_amd has no CPU path (the CPU oracle lives in oracle/ for tests only)")
     rank, world, local = vdist.init()
@@ -98,6 +98,8 @@ def main(argv=None):
         model = VideoMusicTransformer(rpr=args.rpr, **common)
     elif args.music_gen_version.startswith("1."):      # generate.py:221-226
         model = VideoMusicTransformer_V1(version_name=args.music_gen_version, rms_norm=args.rms_norm, **common)
+    elif args.music_gen_version.startswith("3."):      # generate.py:233-238
+        model = VideoMusicTransformer_V3(version_name=args.music_gen_version, rms_norm=args.rms_norm, **common)
     else:                                              # generate.py:227-232
         model = VideoMusicTransformer_V2(version_name=args.music_gen_version, rms_norm=args.rms_norm, **common)
     if args.synthetic or args.synthetic_weights:

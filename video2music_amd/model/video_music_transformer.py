@@ -589,9 +589,19 @@ class VideoMusicTransformer_V2(nn.Module):
                         resid=pos_rows)
         src = vf.view(B, S, d).permute(1, 0, 2).contiguous().view(S * B, d)
         for lyr in self.transformer.encoder.layers:
-            src = self._ln(self._attention(src, src, lyr.self_attn, S, S, B, False, src), lyr.norm1)
-            src = self._ln(self._ff(src, lyr.ff, S, B), lyr.norm2, resid=src)
+            src = self._enc_layer(src, lyr, S, B)
         return self._ln(src, self.transformer.encoder.norm), B, S
+
+    def _enc_layer(self, src, lyr, S, B):
+        """Post-norm encoder layer (custom_transformer.py:1233-1240)."""
+        src = self._ln(self._attention(src, src, lyr.self_attn, S, S, B, False, src), lyr.norm1)
+        return self._ln(self._ff(src, lyr.ff, S, B), lyr.norm2, resid=src)
+
+    def _dec_layer(self, t, memory, lyr, L, S, B):
+        """Post-norm decoder layer (custom_transformer.py:1262-1276)."""
+        t = self._ln(self._attention(t, t, lyr.self_attn, L, L, B, True, t), lyr.norm1)
+        t = self._ln(self._attention(t, memory, lyr.cross_attn, L, S, B, False, t), lyr.norm2)
+        return self._ln(self._ff(t, lyr.ff, L, B), lyr.norm3, resid=t)
 
     def _decode(self, x_root, x_attr, feature_key, memory, B, S):
         """Chord stream + decoder stack + Wout (:437-452, :490-516) over a precomputed encoder memory."""
@@ -606,9 +616,7 @@ class VideoMusicTransformer_V2(nn.Module):
                              self._wkey, self.Linear_chord.bias.detach(), self._pe_chord)
         t = xf.view(B, L, d).permute(1, 0, 2).contiguous().view(L * B, d)
         for lyr in self.transformer.decoder.layers:
-            t = self._ln(self._attention(t, t, lyr.self_attn, L, L, B, True, t), lyr.norm1)
-            t = self._ln(self._attention(t, memory, lyr.cross_attn, L, S, B, False, t), lyr.norm2)
-            t = self._ln(self._ff(t, lyr.ff, L, B), lyr.norm3, resid=t)
+            t = self._dec_layer(t, memory, lyr, L, S, B)
         t = self._ln(t, self.transformer.decoder.norm)
         t = t.view(L, B, d).permute(1, 0, 2).contiguous().view(B * L, d)
         return ops.linear(t, self.Wout.weight.detach(), self.Wout.bias.detach()).view(B, L, CHORD_SIZE)
@@ -948,3 +956,148 @@ class VideoMusicTransformer_V1(VideoMusicTransformer_V2):
         # the RoPE cache caps the chord sequence at max_sequence_video, the positional table at max_sequence_chord
         self._max_dec = min(max_sequence_video, max_sequence_chord) if self._use_rope else max_sequence_chord
         self._derived_sig = None
+
+
+# ==================================================================================================
+# VideoMusicTransformer_V3 (last widening): differential attention, not KV-cacheable
+# ==================================================================================================
+class _DiffAttnParams(nn.Module):
+    """Keys of custom_transformer.DifferentialMultiheadAttention (:610-647): bias-free q/k (E -> 2E), v, out projections,
+    the four lambda vectors and the sub-layer RMSNorm over head_dim."""
+
+    def __init__(self, d_model, head_dim, depth):
+        super().__init__()
+        for n in ("lambda_q1", "lambda_k1", "lambda_q2", "lambda_k2"):
+            setattr(self, n, nn.Parameter(torch.zeros(head_dim).normal_(mean=0, std=0.1)))
+        self.k_proj = nn.Linear(d_model, 2 * d_model, bias=False)
+        self.q_proj = nn.Linear(d_model, 2 * d_model, bias=False)
+        self.v_proj = nn.Linear(d_model, d_model, bias=False)
+        self.out_proj = nn.Linear(d_model, d_model, bias=False)
+        from .custom_transformer import RMSNorm
+        self.subln = RMSNorm(head_dim, eps=1e-5, elementwise_affine=True)
+        self.lambda_init = 0.8 - 0.6 * math.exp(-0.3 * depth)                   # lambda_init_fn (:607-608)
+        for q in (self.k_proj, self.q_proj, self.v_proj, self.out_proj):
+            nn.init.xavier_uniform_(q.weight)
+
+    def lambda_full(self):
+        """exp(lq1.lk1) - exp(lq2.lk2) + lambda_init (:818-820); a host scalar, recomputed when a lambda vector changes."""
+        ps = (self.lambda_q1, self.lambda_k1, self.lambda_q2, self.lambda_k2)
+        sig = tuple((q.data_ptr(), q._version) for q in ps)
+        if getattr(self, "_lam_sig", None) != sig:
+            q1, k1, q2, k2 = (q.detach().float().cpu() for q in ps)
+            self._lam = float(torch.exp(torch.sum(q1 * k1)) - torch.exp(torch.sum(q2 * k2)) + self.lambda_init)
+            self._lam_sig = sig
+        return self._lam
+
+
+class VideoMusicTransformer_V3(VideoMusicTransformer_V2):
+    """Reference ``VideoMusicTransformer_V3`` (model/video_music_transformer.py:611-909), versions '3.0', '3.1', '3.2', eval
+    mode.  RMSNorm everywhere, RoPE built for dim = 2 d_model, three GLU layers then SharedMoELayer(6, top-2, balancing
+    buffer) layers; the decoder's (and, for '3.1' / '3.2', the encoder's) attentions are
+    ``DifferentialMultiheadAttention`` (custom_transformer.py:610-831) with lambda_init by layer depth; '3.2' is pre-norm.
+
+    Differential attention as the reference wires it: q, k = x Wq^T, x Wk^T (E -> 2E, no bias) rotated through the raw
+    (2H, L, B, hd) view, then read through the raw (B, L, 2H, hd) view; v through the raw (B, S, H, hd) view; head pair
+    (2h, 2h+1) gives softmax maps A1, A2 and out = RMSNorm_hd((A1 - lambda A2) v_h) (1 - lambda_init); the (B, H, L, hd)
+    result is then *viewed* as (L, B, E) (:827) -- which hands row l data of positions other than l, later ones included,
+    so a position's output depends on the current length and the model cannot be KV-cached: ``generate`` re-runs the
+    decoder on the whole prefix every step (the encoder still runs once).  Here both maps run on the tiled attention
+    kernel (two launches over strided views, no copies), the subtraction + sub-norm + scale is one kernel
+    (``amt_diff_subln_fwd``) writing the (B, H, L, hd) layout the reference reinterprets.
+    """
+
+    def __init__(self, version_name="3.0", n_layers=6, num_heads=8, d_model=512, dim_feedforward=1024, dropout=0.1,
+                 max_sequence_midi=2048, max_sequence_video=300, max_sequence_chord=300, total_vf_dim=0, rms_norm=False,
+                 scene_embed=False, chord_embed=False, dropTokenRate=0.0):
+        nn.Module.__init__(self)
+        if version_name not in ("3.0", "3.1", "3.2"):
+            raise ValueError("the reference builds an encoder for '3.0', '3.1' and '3.2' only (:672-690)")
+        if scene_embed or dropTokenRate != 0.0:
+            raise NotImplementedError("scene_embed / dropTokenRate (a random mask applied even in eval) are outside this path")
+        if n_layers < 3:
+            raise ValueError("the reference builds 3 shallow + (n_layers-3) deep layers")
+        from .custom_transformer import RMSNorm
+        from .moe import GLUExpert, SharedMoELayer
+        from .rotate_operation import RotaryPositionalEmbeddings
+        self.nlayers, self.nhead, self.d_model, self.d_ff, self.dropout = n_layers, num_heads, d_model, dim_feedforward, dropout
+        self.max_seq_midi, self.max_seq_video, self.max_seq_chord = max_sequence_midi, max_sequence_video, max_sequence_chord
+        self.scene_embed, self.chord_embed, self.dropTokenRate, self.version_name = scene_embed, chord_embed, dropTokenRate, version_name
+        self.total_vf_dim = total_vf_dim
+        self.n_experts, self.n_experts_per_token = 6, 2
+        self._learned_pos, self._use_rope = False, True
+        self.pre_norm = version_name == "3.2"
+        if chord_embed:
+            self.chord_embedding_model = nn.Embedding(CHORD_SIZE, d_model)
+            self.chord_embedding_model.weight.requires_grad_(False)
+            self._register_load_state_dict_pre_hook(self._resize_chord_table)
+        self.embedding = nn.Embedding(CHORD_SIZE, d_model)
+        self.embedding_root = nn.Embedding(CHORD_ROOT_SIZE, d_model)
+        self.embedding_attr = nn.Embedding(CHORD_ATTR_SIZE, d_model)
+        self.Linear_vis = nn.Linear(total_vf_dim, d_model)
+        self.Linear_chord = nn.Linear(d_model + 1, d_model)
+        self.condition_linear = nn.Linear(1, d_model)
+        hd = d_model // num_heads
+
+        def ff(i):
+            if i < 3:
+                return GLUExpert(d_model, dim_feedforward, dropout)
+            return SharedMoELayer(GLUExpert(d_model, dim_feedforward, dropout), d_model, n_experts=self.n_experts,
+                                  n_experts_per_token=2, dropout=dropout, balancing=True)
+
+        self.transformer = _TransformerParamsV2(d_model, num_heads, n_layers, ff, norm=RMSNorm)
+        for i, lyr in enumerate(self.transformer.decoder.layers):
+            lyr.self_attn, lyr.cross_attn = _DiffAttnParams(d_model, hd, i), _DiffAttnParams(d_model, hd, i)
+        if version_name != "3.0":                               # '3.0' keeps CustomMultiheadAttention in the encoder (:672-676)
+            for i, lyr in enumerate(self.transformer.encoder.layers):
+                lyr.self_attn = _DiffAttnParams(d_model, hd, i)
+        self.Wout = nn.Linear(d_model, CHORD_SIZE)
+        self.softmax = nn.Softmax(dim=-1)
+        rope = RotaryPositionalEmbeddings(2 * d_model, max_sequence_video)          # dim = 2 d_model (:658)
+        self.register_buffer("_rope_cache", rope.cache.clone(), persistent=False)
+        self._max_dec = max_sequence_video
+        self._derived_sig = None
+
+    def _attention(self, xq, xkv, a, Lq, Lk, B, causal, resid):
+        from .. import ops
+        if not isinstance(a, _DiffAttnParams):
+            return super()._attention(xq, xkv, a, Lq, Lk, B, causal, resid)
+        E, H = self.d_model, self.nhead
+        hd = E // H
+        q = ops.linear(xq, a.q_proj.weight.detach())                                 # (Lq*B, 2E)
+        k = ops.linear(xkv, a.k_proj.weight.detach())
+        v = ops.linear(xkv, a.v_proj.weight.detach())                                # (Lk*B, E)
+        q = ops.rope(q.view(2 * H, Lq, B, hd), self._rope_cache).view(-1)            # raw (2H, L, B, hd) view (:779-785)
+        k = ops.rope(k.view(2 * H, Lk, B, hd), self._rope_cache).view(-1)
+        # raw (B, L, 2H, hd) / (B, S, H, hd) views of the same memory (:787-789): flat row b*L + l, head j at column j*hd;
+        # even heads at head stride 2 hd from offset 0, odd heads from offset hd; outputs (B, H, Lq, hd) contiguous
+        o1 = torch.empty(B, H, Lq, hd, device=xq.device, dtype=torch.float32)
+        o2 = torch.empty_like(o1)
+        st = (Lq * 2 * E, 2 * hd, 2 * E, Lk * 2 * E, 2 * hd, 2 * E, Lk * E, hd, E, H * Lq * hd, Lq * hd, hd)
+        scale = hd ** -0.5
+        ops.attention(q, k, v, st, B, H, Lq, Lk, hd, causal, scale, o1)
+        ops.attention(q[hd:], k[hd:], v, st, B, H, Lq, Lk, hd, causal, scale, o2)
+        y = ops.diff_subln(o1, o2, a.subln.weight.detach(), a.lambda_full(), 1.0 - a.lambda_init, eps=a.subln.eps)
+        return ops.linear(y.view(Lq * B, E), a.out_proj.weight.detach(), resid=resid)  # attn.view(tgt_len, bsz, E) (:827)
+
+    def _enc_layer(self, src, lyr, S, B):
+        if not self.pre_norm:
+            return super()._enc_layer(src, lyr, S, B)
+        from .. import ops
+        h = self._ln(src, lyr.norm1)                                                 # pre-norm (:1241-1249)
+        src = self._attention(h, h, lyr.self_attn, S, S, B, False, src)
+        return ops.add(src, self._ff(self._ln(src, lyr.norm2), lyr.ff, S, B))
+
+    def _dec_layer(self, t, memory, lyr, L, S, B):
+        if not self.pre_norm:
+            return super()._dec_layer(t, memory, lyr, L, S, B)
+        from .. import ops
+        h = self._ln(t, lyr.norm1)                                                   # pre-norm (:1277-1292)
+        t = self._attention(h, h, lyr.self_attn, L, L, B, True, t)
+        t = self._attention(self._ln(t, lyr.norm2), memory, lyr.cross_attn, L, S, B, False, t)
+        return ops.add(t, self._ff(self._ln(t, lyr.norm3), lyr.ff, L, B))
+
+    def generate(self, *args, use_cache=False, use_graph=False, **kw):
+        """The reference loop; every step re-runs the decoder on the whole prefix (see the class docstring)."""
+        if use_cache:
+            raise NotImplementedError("V3's attention output view makes earlier rows depend on the sequence length: no KV cache")
+        return super().generate(*args, use_cache=False, use_graph=False, **kw)

@@ -33,6 +33,20 @@ def layernorm(x, w, b, resid=None, eps=1e-5):
     return y
 
 
+def diff_subln(o1, o2, w, lam, out_scale, eps=1e-5):
+    """RMSNorm_hd(o1 - lam * o2) * w * out_scale; o1 / o2 (..., hd) contiguous."""
+    hd = o1.shape[-1]
+    y = torch.empty_like(o1)
+    _lib.call("amt_diff_subln_fwd", p(o1), p(o2), p(w), p(y), o1.numel() // hd, hd, float(lam), float(out_scale), float(eps), _st())
+    return y
+
+
+def add(a, b):
+    y = torch.empty_like(a)
+    _lib.call("amt_add_fwd", p(a), p(b), p(y), a.numel(), _st())
+    return y
+
+
 def rmsnorm(x, w, resid=None, eps=1e-6):
     """RMSNorm(x (+ resid)) * w (custom_transformer.py:27-45)."""
     rows, dim = x.shape
