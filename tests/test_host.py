@@ -99,8 +99,9 @@ def test_v3_state_dict_matches_reference_key_counts(golden):
 
 
 def test_unsupported_constructor_options_raise():
-    with pytest.raises(NotImplementedError):
-        VideoMusicTransformer(total_vf_dim=1287, rpr=False)
+    plain = VideoMusicTransformer(rpr=False, **{k: v for k, v in CFG1.items() if k != "rpr"})       # torch's stock decoder layers: no Er
+    assert not any(k.endswith(".Er") for k in plain.state_dict())
+    assert len(plain.state_dict()) == len(VideoMusicTransformer(**CFG1).state_dict()) - CFG1["n_layers"]
     with pytest.raises(NotImplementedError):
         VideoMusicTransformer(total_vf_dim=1287, rpr=True, chord_embed=True)
 

@@ -409,3 +409,27 @@ def test_device_categorical_draw_extremes_and_seed():
     mn = m.generate_batch(*args, target_seq_length=T, beam=0, sampler="multinomial")
     assert int(mn[:, 1:].min()) >= 1 and int(mn.max()) < C.CHORD_END
     assert not bool(((mn[:, 2:] == mn[:, 1:-1]) & (mn[:, 1:-1] == mn[:, :-2])).any())
+
+
+def test_rpr_false_vs_reference_golden(golden):
+    """rpr=False (the class default): torch's stock decoder layers, i.e. no relative-position table -- forward, G1, G2 of
+    the reference class built that way."""
+    g = golden("g_norpr.npz")
+    cfg = dict(CFG1, rpr=False)
+    m = VideoMusicTransformer(**cfg).eval()
+    shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    assert len(shapes) == int(g["n_keys"])
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=0).items()}, strict=False)
+    m = m.cuda()
+    key = np.array([[0.0], [1.0], [0.0]], dtype=np.float32)
+    f = cu(feats_t(synthetic.synthetic_features(3, seed=1234), key=key))
+    root, attr = torch.from_numpy(g["root"]).cuda(), torch.from_numpy(g["attr"]).cuda()
+    with torch.no_grad():
+        y = m(root, root, attr, f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"])
+    err = np.abs(y.cpu().numpy() - g["logits"]).max()
+    assert err < LOGIT_TOL, err
+    kw = dict(feature_semantic_list=f["semantic"][:1], feature_key=f["key"][0], feature_scene_offset=f["scene_offset"][:1],
+              feature_motion=f["motion"][:1], feature_emotion=f["emotion"][:1], primer=torch.tensor([1]), primer_root=torch.tensor([1]),
+              primer_attr=torch.tensor([0]), target_seq_length=48)
+    assert np.array_equal(m.generate(beam=1, **kw).cpu().numpy(), g["g1"])
+    assert np.array_equal(m.generate(beam=0, sampler="argmax", **kw).cpu().numpy(), g["g2"])

@@ -117,9 +117,9 @@ class VideoMusicTransformer(nn.Module):
                  max_sequence_chord=300, total_vf_dim=0, rpr=False, scene_embed=False,
                  chord_embed=False):
         super().__init__()
-        if not rpr:
-            raise NotImplementedError("video2music_amd implements the rpr=True AMT (the configuration the reference "
-                                      "ships and BASELINE.json names); rpr=False selects torch's stock decoder")
+        # rpr=False (the class default; generate.py passes RPR=True) selects torch's stock decoder layers (:957-962): the same
+        # layer without the relative-position table.  It runs on the same kernels with an all-zero Er (the bias q.Er is then
+        # exactly 0), which is not part of the state_dict.
         if scene_embed or chord_embed:
             raise NotImplementedError("scene_embed / chord_embed are outside the hot path (SURVEY.md §2 row 28)")
         self.nlayers = n_layers
@@ -143,7 +143,7 @@ class VideoMusicTransformer(nn.Module):
         self.positional_encoding = PositionalEncoding(d_model, dropout, max_sequence_chord)
         self.positional_encoding_video = PositionalEncoding(d_model, dropout, max_sequence_video)
         self.condition_linear = nn.Linear(1, d_model)
-        self.transformer = _TransformerParams(d_model, num_heads, n_layers, dim_feedforward, max_sequence_chord)
+        self.transformer = _TransformerParams(d_model, num_heads, n_layers, dim_feedforward, max_sequence_chord if rpr else None)
         self.Wout_root = nn.Linear(d_model, CHORD_ROOT_SIZE)
         self.Wout_attr = nn.Linear(d_model, CHORD_ATTR_SIZE)
         self.Wout = nn.Linear(d_model, CHORD_SIZE)
@@ -179,6 +179,12 @@ class VideoMusicTransformer(nn.Module):
                 t = t.detach().to(torch.float32).contiguous()
                 shape = (C.c_int64 * t.dim())(*t.shape)
                 _lib.call("amt_load_weight", self._handle, name.encode(), _lib.ptr(t), t.dim(), shape)
+            if not self.rpr:
+                zero = torch.zeros(self.max_seq_chord, self.d_model // self.nhead, device=dev)
+                shape = (C.c_int64 * 2)(*zero.shape)
+                for i in range(self.nlayers):
+                    _lib.call("amt_load_weight", self._handle, f"transformer.decoder.layers.{i}.self_attn.Er".encode(), _lib.ptr(zero), 2, shape)
+                self._zero_er = zero
             _lib.call("amt_finalize", self._handle)
             self._weights_sig = sig
         return self._handle
