@@ -48,6 +48,20 @@ def main():
             feat = m.get_feature(sem, None, None, emo)
         out.update({f"sem_B{B}_S{S}": sem.numpy(), f"emo_B{B}_S{S}": emo.numpy(), f"lnnd_B{B}_S{S}": ln_nd.numpy(),
                     f"inst_B{B}_S{S}": inst.numpy(), f"feat_B{B}_S{S}": feat.numpy()})
+    # the other Mamba regModels: same inputs as the (3, 17) case, one golden each
+    rs = np.random.RandomState(11)
+    sem = torch.from_numpy(rs.standard_normal((3, 50, 24)).astype(np.float32))
+    z = rs.standard_normal((3, 50, 6))
+    emo = torch.from_numpy((np.exp(z) / np.exp(z).sum(-1, keepdims=True)).astype(np.float32))
+    out["alt_sem"], out["alt_emo"] = sem.numpy(), emo.numpy()
+    for rm in ("bimamba", "mamba", "mamba+"):
+        mm = VideoRegression(max_sequence_video=300, **dict(CFG, regModel=rm)).eval()
+        shp = [(k, tuple(v.shape)) for k, v in mm.state_dict().items()]
+        mm.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shp, seed=5).items()}, strict=True)
+        with torch.no_grad():
+            ln_nd, inst = mm(sem, torch.zeros(3, 50), torch.zeros(3, 50, 512), emo)
+        out[f"alt_{rm}_lnnd"], out[f"alt_{rm}_inst"] = ln_nd.numpy(), inst.numpy()
+        out[f"alt_{rm}_keys"] = np.array([k for k, _ in shp])
     np.savez_compressed(os.path.join(REPO, "tests", "golden", "g_reg.npz"), **out)
     print("wrote g_reg.npz", len(out), [(k, v) for k, v in shapes][:6])
 

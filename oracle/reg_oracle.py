@@ -74,34 +74,59 @@ def mamba_block(x, sd, p, version=1, collect=None):
     return linear(out, sd[p + "out_proj.weight"], sd.get(p + "out_proj.bias"))
 
 
-def bimamba_layer(x, sd, p):
+def bimamba_layer(x, sd, p, version=1):
     """BiMambaEncoderLayer_V1.forward, norm_first=False (bimamba.py:171-196); dropout is identity in eval."""
-    xf = mamba_block(x, sd, p + "mamba_forward.")
+    xf = mamba_block(x, sd, p + "mamba_forward.", version)
     xf = layer_norm(xf + x, sd[p + "norm1.weight"], sd[p + "norm1.bias"])
-    xb = mamba_block(torch.flip(x, dims=[1]), sd, p + "mamba_backward.")
+    xb = mamba_block(torch.flip(x, dims=[1]), sd, p + "mamba_backward.", version)
     xb = layer_norm(torch.flip(xb, dims=[1]) + x, sd[p + "norm2.weight"], sd[p + "norm2.bias"])
     s = xf + xb
     f = linear(torch.relu(linear(s, sd[p + "ffn.0.weight"], sd[p + "ffn.0.bias"])), sd[p + "ffn.3.weight"], sd[p + "ffn.3.bias"])
     return layer_norm(f + s, sd[p + "norm3.weight"], sd[p + "norm3.bias"])
 
 
+def bimamba_layer_v0(x, sd, p):
+    """BiMambaEncoderLayer.forward (bimamba.py:61-100), the layer of use_version 0: an FFN + norm pair per direction;
+    `ffn2` is applied to the forward branch's x_f (:94), as written."""
+    def ffn(t, q):
+        return linear(torch.relu(linear(t, sd[p + q + ".0.weight"], sd[p + q + ".0.bias"])), sd[p + q + ".3.weight"], sd[p + q + ".3.bias"])
+    xf = layer_norm(mamba_block(x, sd, p + "mamba_forward.", 0) + x, sd[p + "norm1.weight"], sd[p + "norm1.bias"])
+    xf = layer_norm(ffn(xf, "ffn1") + xf, sd[p + "norm2.weight"], sd[p + "norm2.bias"])
+    xb = torch.flip(mamba_block(torch.flip(x, dims=[1]), sd, p + "mamba_backward.", 0), dims=[1])
+    xb = layer_norm(xb + x, sd[p + "norm3.weight"], sd[p + "norm3.bias"])
+    xb = layer_norm(ffn(xf, "ffn2") + xb, sd[p + "norm4.weight"], sd[p + "norm4.bias"])
+    return xf + xb
+
+
 def n_layers_of(sd):
     n = 0
-    while f"model.layers.{n}.norm1.weight" in sd:
+    while f"model.layers.{n}.norm1.weight" in sd or f"model.layers.{n}.norm.weight" in sd:
         n += 1
     return n
 
 
-def forward(sd, sem, emotion, collect=None):
+def residual_block(x, sd, p, version):
+    """ResidualBlock.forward (mamba.py:139-142): mixer(RMSNorm(x)) + x, RMSNorm eps 1e-5 (:472-489)."""
+    h = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * sd[p + "norm.weight"]
+    return mamba_block(h, sd, p + "mixer.", version) + x
+
+
+def forward(sd, sem, emotion, collect=None, reg_model="bimamba+"):
     """VideoRegression.forward (video_regression.py:199-245): returns (loudness_notedensity (B,S,2), instrument (B,S,40)).
-    Scene offset and motion are accepted by the reference's signature but not used (:205-213 are commented out)."""
+    Scene offset and motion are accepted by the reference's signature but not used (:205-213 are commented out).
+    reg_model: 'bimamba+' / 'bimamba' (BiMambaEncoder) or 'mamba+' / 'mamba' (Mamba stack); '+' = use_version 1."""
+    version = 1 if reg_model.endswith("+") else 0
     sd = {k: v.float() for k, v in sd.items()}
     vf = torch.cat([sem.float(), emotion.float()], dim=-1)
     x = linear(vf, sd["in_proj.0.weight"], sd["in_proj.0.bias"])
     if collect is not None:
         collect["in_proj"] = x
     for l in range(n_layers_of(sd)):
-        x = bimamba_layer(x, sd, f"model.layers.{l}.")
+        p = f"model.layers.{l}."
+        if reg_model.startswith("bi"):
+            x = bimamba_layer(x, sd, p, 1) if version == 1 else bimamba_layer_v0(x, sd, p)
+        else:
+            x = residual_block(x, sd, p, version)
         if collect is not None:
             collect[f"layer{l}"] = x
     ln_nd = linear(x, sd["regressor.weight"], sd["regressor.bias"])

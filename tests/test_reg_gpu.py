@@ -94,3 +94,20 @@ def test_rejects_unbuilt_variants():
     with pytest.raises(ValueError):
         m, _ = build(dict(n_layers=1, d_model=32, d_hidden=64, total_vf_dim=30, regModel="bimamba+"), seed=0)
         m(torch.zeros(1, 4, 20).cuda(), None, None, torch.zeros(1, 4, 6).cuda())
+
+
+@pytest.mark.parametrize("rm", ["bimamba", "mamba", "mamba+"])
+def test_other_mamba_regmodels_vs_reference_golden(golden, rm):
+    g = golden("g_reg.npz")
+    m, _ = build(dict(n_layers=2, d_model=32, d_hidden=64, total_vf_dim=30, regModel=rm), seed=5)
+    assert list(m.state_dict()) == [str(k) for k in g[f"alt_{rm}_keys"]]
+    with torch.no_grad():
+        ln_nd, inst = m(torch.from_numpy(g["alt_sem"]).cuda(), None, None, torch.from_numpy(g["alt_emo"]).cuda())
+    assert (ln_nd.cpu() - torch.from_numpy(g[f"alt_{rm}_lnnd"])).abs().max().item() < 5e-5
+    assert (inst.cpu() - torch.from_numpy(g[f"alt_{rm}_inst"])).abs().max().item() < 5e-5
+
+
+def test_unbuilt_regmodels_say_so():
+    for rm in ("bilstm", "gru", "moemamba", "minGRU"):
+        with pytest.raises(NotImplementedError):
+            VideoRegression(total_vf_dim=30, regModel=rm)

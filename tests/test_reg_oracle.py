@@ -40,3 +40,21 @@ def test_scan_is_causal_and_backward_branch_sees_the_future(golden):
     assert torch.equal(a[:, :-1], b[:, :-1]) and not torch.equal(a[:, -1], b[:, -1])
     la, lb = R.bimamba_layer(x, sd, "model.layers.0."), R.bimamba_layer(x2, sd, "model.layers.0.")
     assert (la[:, 0] - lb[:, 0]).abs().max() > 0
+
+
+def alt_sd(g, rm, seed=5):
+    from video2music_amd.model.video_regression import VideoRegression
+    m = VideoRegression(n_layers=2, d_model=32, d_hidden=64, total_vf_dim=30, regModel=rm)
+    shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    assert [k for k, _ in shapes] == [str(k) for k in g[f"alt_{rm}_keys"]]       # the reference's key order, too
+    return {k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=seed).items()}
+
+
+def test_oracle_equals_reference_for_the_other_mamba_regmodels(golden):
+    """'bimamba' (original gate), 'mamba' / 'mamba+' (one-directional ResidualBlock stacks)."""
+    g = golden("g_reg.npz")
+    for rm in ("bimamba", "mamba", "mamba+"):
+        sd = alt_sd(g, rm)
+        ln_nd, inst = R.forward(sd, torch.from_numpy(g["alt_sem"]), torch.from_numpy(g["alt_emo"]), reg_model=rm)
+        assert (ln_nd - torch.from_numpy(g[f"alt_{rm}_lnnd"])).abs().max() < 2e-5, rm
+        assert (inst - torch.from_numpy(g[f"alt_{rm}_inst"])).abs().max() < 2e-5, rm

@@ -1,6 +1,8 @@
-"""`VideoRegression` (reference model/video_regression.py:104-245) for `regModel='bimamba+'`, the default regression
-head of both callers (utilities/argument_generate_funcs.py:87-91, video2music.py:651): per video frame it predicts
-(note density, loudness) and 40 instrument probabilities from cat(semantic, emotion) — SURVEY.md §8 row f2.
+"""`VideoRegression` (reference model/video_regression.py:104-245) for the Mamba regModels: 'bimamba+' -- the default
+regression head of both callers (utilities/argument_generate_funcs.py:87-91, video2music.py:651) --, 'bimamba' (the same
+encoder over the original Mamba gate), and the one-directional stacks 'mamba' / 'mamba+' (mamba.py:66-100,131-147:
+x + MambaBlock(RMSNorm(x)) per layer).  Per video frame it predicts (note density, loudness) and 40 instrument
+probabilities from cat(semantic, emotion) — SURVEY.md §8 row f2.
 
 The module keeps the reference's parameter names (so `load_state_dict(torch.load(path))` works) and composes the
 library's kernels; no torch arithmetic runs in `forward`:
@@ -50,26 +52,66 @@ class _BiMambaLayerParams(nn.Module):
         self.ffn = nn.Sequential(nn.Linear(d_model, d_hidden), nn.ReLU(), nn.Dropout(0.0), nn.Linear(d_hidden, d_model))
 
 
-class _BiMambaEncoderParams(nn.Module):
-    def __init__(self, d_model, d_hidden, n_layers):
+class _RMSWeight(nn.Module):
+    """mamba.py's RMSNorm (:472-489): a gain vector, eps 1e-5."""
+
+    def __init__(self, d_model, eps=1e-5):
         super().__init__()
-        self.layers = nn.ModuleList([_BiMambaLayerParams(d_model, d_hidden) for _ in range(n_layers)])
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(d_model))
+
+
+class _ResidualBlockParams(nn.Module):
+    """ResidualBlock (mamba.py:131-147): keys mixer.*, norm.weight."""
+
+    def __init__(self, d_model):
+        super().__init__()
+        self.mixer = _MambaBlockParams(d_model)
+        self.norm = _RMSWeight(d_model)
+
+
+class _MambaStackParams(nn.Module):
+    def __init__(self, d_model, n_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([_ResidualBlockParams(d_model) for _ in range(n_layers)])
+
+
+class _BiMambaLayerV0Params(nn.Module):
+    """BiMambaEncoderLayer (bimamba.py:33-59), the layer of use_version 0 ('bimamba'): one FFN + norm pair per direction."""
+
+    def __init__(self, d_model, d_hidden):
+        super().__init__()
+        self.mamba_forward = _MambaBlockParams(d_model)
+        self.mamba_backward = _MambaBlockParams(d_model)
+        self.norm1, self.norm2, self.norm3, self.norm4 = (nn.LayerNorm(d_model) for _ in range(4))
+        self.ffn1 = nn.Sequential(nn.Linear(d_model, d_hidden), nn.ReLU(), nn.Dropout(0.0), nn.Linear(d_hidden, d_model))
+        self.ffn2 = nn.Sequential(nn.Linear(d_model, d_hidden), nn.ReLU(), nn.Dropout(0.0), nn.Linear(d_hidden, d_model))
+
+
+class _BiMambaEncoderParams(nn.Module):
+    def __init__(self, d_model, d_hidden, n_layers, version=1):
+        super().__init__()
+        layer = _BiMambaLayerParams if version == 1 else _BiMambaLayerV0Params          # bimamba.py:16-19
+        self.layers = nn.ModuleList([layer(d_model, d_hidden) for _ in range(n_layers)])
 
 
 class VideoRegression(nn.Module):
     def __init__(self, n_layers=2, d_model=64, d_hidden=1024, dropout=0.1, use_KAN=False, max_sequence_video=300,
                  total_vf_dim=0, regModel="bilstm", scene_embed=False, chord_embed=False):
         super().__init__()
-        if regModel != "bimamba+":
-            raise NotImplementedError("only regModel='bimamba+' (the callers' default) is built; the LSTM/GRU/Mamba/MoE variants "
-                                      "of video_regression.py:124-178 are not")
+        if regModel not in ("bimamba+", "bimamba", "mamba", "mamba+"):
+            raise NotImplementedError("built: regModel 'bimamba+' (the callers' default), 'bimamba', 'mamba', 'mamba+'; the LSTM / GRU / "
+                                      "CNN-GRU / minGRU and the MoE-Mamba variants of video_regression.py:124-178 are not")
+        self._version = 1 if regModel.endswith("+") else 0           # MambaConfig.use_version: 1 = the Mamba+ gate
+        self._bidirectional = regModel.startswith("bi")
         if use_KAN or scene_embed or chord_embed:
             raise NotImplementedError("use_KAN / scene_embed / chord_embed are outside this path")
         if d_model % 32 != 0 or d_hidden % 32 != 0:
             raise ValueError("d_model and d_hidden must be multiples of 32 (GEMM K step)")
         self.n_layers, self.d_model, self.d_hidden = n_layers, d_model, d_hidden
         self.max_seq_video, self.total_vf_dim, self.regModel = max_sequence_video, total_vf_dim, regModel
-        self.model = _BiMambaEncoderParams(d_model, d_hidden, n_layers)
+        self.model = (_BiMambaEncoderParams(d_model, d_hidden, n_layers, self._version) if self._bidirectional
+                      else _MambaStackParams(d_model, n_layers))
         self.in_proj = nn.Sequential(nn.Linear(total_vf_dim, d_model), nn.Dropout(dropout))
         self.regressor = nn.Linear(d_model, 2)
         self.classifier = nn.Sequential(nn.Linear(d_model, INSTRUMENT_SIZE), nn.Sigmoid())
@@ -77,7 +119,8 @@ class VideoRegression(nn.Module):
 
     # zero-padded copies of the weights whose K (or row count) does not fit the GEMM's steps (rebuilt when they change)
     def _derived(self):
-        blocks = [m for l in self.model.layers for m in (l.mamba_forward, l.mamba_backward)]
+        blocks = ([m for l in self.model.layers for m in (l.mamba_forward, l.mamba_backward)] if self._bidirectional
+                  else [l.mixer for l in self.model.layers])
         ws = [self.in_proj[0].weight] + [m.dt_proj.weight for m in blocks]
         xs = [m.x_proj.weight for m in blocks]
         sig = tuple((w.data_ptr(), w._version) for w in ws + xs)
@@ -110,7 +153,7 @@ class VideoRegression(nn.Module):
         dbc = ops.linear_ex(xc, wx)
         draw = ops.linear_ex(dbc, wdt, K=32)
         g = ops.selective_scan(xc, draw, m.dt_proj.bias.detach(), m.A_log.detach(), dbc, R, m.D.detach(), xz, B, L,
-                               version=1, reverse=reverse)
+                               version=self._version, reverse=reverse)
         return ops.linear_ex(g, m.out_proj.weight.detach(), m.out_proj.bias.detach(), resid=resid)
 
     def get_feature(self, feature_semantic_list, feature_scene_offset, feature_motion, feature_emotion):
@@ -126,6 +169,21 @@ class VideoRegression(nn.Module):
             raise ValueError(f"semantic ({sem.shape[2]}) + emotion ({emo.shape[2]}) features != total_vf_dim ({self.total_vf_dim})")
         vf = ops.concat2(sem.view(B * S, -1), emo.view(B * S, -1), self._Fpad)
         x = ops.linear_ex(vf, self._Win, self.in_proj[0].bias.detach())
+        if not self._bidirectional:                     # Mamba.forward (mamba.py:73-78): x = mixer(norm(x)) + x per layer
+            for i, lyr in enumerate(self.model.layers):
+                h = ops.rmsnorm(x, lyr.norm.weight.detach(), eps=lyr.norm.eps)
+                x = self._mamba(h, lyr.mixer, self._Wdt[i], self._Wx[i], B, S, x, False)
+            return x.view(B, S, self.d_model)
+        if self._version == 0:                          # BiMambaEncoderLayer.forward (bimamba.py:61-100)
+            ln = lambda t, n, post=None: ops.layernorm_post(t, n.weight.detach(), n.bias.detach(), post=post, eps=n.eps)
+            ffn = lambda t, f, resid: ops.linear_ex(ops.linear_ex(t, f[0].weight.detach(), f[0].bias.detach(), act=1),
+                                                    f[3].weight.detach(), f[3].bias.detach(), resid=resid)
+            for i, lyr in enumerate(self.model.layers):
+                xf = ln(self._mamba(x, lyr.mamba_forward, self._Wdt[2 * i], self._Wx[2 * i], B, S, x, False), lyr.norm1)
+                xf = ln(ffn(xf, lyr.ffn1, xf), lyr.norm2)
+                xb = ln(self._mamba(x, lyr.mamba_backward, self._Wdt[2 * i + 1], self._Wx[2 * i + 1], B, S, x, True), lyr.norm3)
+                x = ln(ffn(xf, lyr.ffn2, xb), lyr.norm4, post=xf)      # ffn2 reads x_f, as written at :94; then x_f + x_b
+            return x.view(B, S, self.d_model)
         for i, lyr in enumerate(self.model.layers):
             xf = ops.layernorm_post(self._mamba(x, lyr.mamba_forward, self._Wdt[2 * i], self._Wx[2 * i], B, S, x, False),
                                     lyr.norm1.weight.detach(), lyr.norm1.bias.detach(), eps=lyr.norm1.eps)
