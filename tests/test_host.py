@@ -158,3 +158,17 @@ def test_shard_bounds_cover_all_clips():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_user_primer_chords_follow_the_reference_rules():
+    """generate.py:291-312: flats -> sharps, quality split after the root, the five short qualities expanded."""
+    want = {"C": "C", "Am": "A:min", "Dm": "D:min", "G": "G", "F#": "F#", "F#m": "F#:min", "Bb": "A#", "Bbm7": "A#:min7",
+            "Ebm6": "D#:min6", "CM7": "C:maj7", "GM6": "G:maj6", "Cdim": "C:dim", "C#sus4": "C#:sus4", "Abmaj7": "G#:maj7"}
+    for typed, name in want.items():
+        assert C.normalise_user_chord(typed) == name, typed
+        assert name in C.CHORD_DIC, name
+    rows = C.primer_from_user_chords(["C", "Am", "Dm", "G"])                 # the reference's custumPrimer (:53)
+    assert rows == [C.primer_from_name(n) for n in ("C", "A:min", "D:min", "G")]
+    assert rows[0] == (1, 1, 0) and rows[1] == (122, 10, 5)                   # plain roots carry attr 0 in a primer (:315-318)
+    a = parse_generate_args(["--primer", "C Am"])[0]
+    assert a.primer == "C Am" and a.num_prime_chord == 30 and not a.primer_from_dataset

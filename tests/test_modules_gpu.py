@@ -113,6 +113,7 @@ def test_generate_cli_reads_feature_files_and_writes_lab(tmp_path):
     from video2music_amd import generate as G, synthetic
     from video2music_amd.dataset import vevo_features as VF
     from video2music_amd.model.video_music_transformer import VideoMusicTransformer
+    from video2music_amd.utilities import constants as C_
     root, out = str(tmp_path / "data"), str(tmp_path / "out")
     write_mini_dataset(root, mini_dataset_content(seed=11))
     argv = ["-dataset_dir", root, "-output_dir", out, "--test_ids", "split:test", "--synthetic_weights", "-music_gen_version", "None",
@@ -139,6 +140,19 @@ def test_generate_cli_reads_feature_files_and_writes_lab(tmp_path):
     ref = m.generate_batch(t("semantic"), key.cuda(), t("scene_offset"), t("motion"), t("emotion"), prim[:, 0:1], prim[:, 1:2], prim[:, 2:3],
                            target_seq_length=24, beam=0, sampler="argmax")
     assert torch.equal(ref.cpu(), toks)
+    # custom primer typed the user's way, and the clips' own first chords (generate.py:286-344, :367-379)
+    base = [a for a in argv if a not in ("--regression", "--midi")]
+    custom = G.main(base + ["--primer", "C Am Dm G"]).cpu()
+    assert custom[:, :4].tolist() == [[C_.CHORD_DIC[n] for n in ("C", "A:min", "D:min", "G")]] * 2
+    rows = torch.tensor([C_.primer_from_user_chords(["C", "Am", "Dm", "G"])] * 2)
+    ref = m.generate_batch(t("semantic"), key.cuda(), t("scene_offset"), t("motion"), t("emotion"), rows[:, :, 0], rows[:, :, 1], rows[:, :, 2],
+                           target_seq_length=24, beam=0, sampler="argmax")
+    assert torch.equal(ref.cpu(), custom)
+    own = G.main(base + ["--primer_from_dataset", "-num_prime_chord", "5"]).cpu()
+    assert np.array_equal(own[:, :5].numpy(), f["chord"][:, :5])
+    pr = [torch.from_numpy(f[k][:, :5]).cuda() for k in ("chord", "chord_root", "chord_attr")]
+    ref = m.generate_batch(t("semantic"), key.cuda(), t("scene_offset"), t("motion"), t("emotion"), *pr, target_seq_length=24, beam=0, sampler="argmax")
+    assert torch.equal(ref.cpu(), own)
 
 
 def test_bench_line_contract(tmp_path):

@@ -88,6 +88,7 @@ def main(argv=None):
         feats = VF.load_clips(args.dataset_dir, names, vis_models="2d/clip_l14p", emo_model=args.emo_model, motion_type=args.motion_type,
                               max_seq_video=args.max_sequence_video, max_seq_chord=args.max_sequence_chord)
         feats["key"] = np.array([[VF.key_from_emotion(e)] for e in feats["emotion"]], dtype=np.float32)
+        own_chords = np.stack([feats["chord"], feats["chord_root"], feats["chord_attr"]], axis=-1)     # (n, Tc, 3)
         feats = {k: feats[k] for k in ("semantic", "key", "scene_offset", "motion", "emotion")}
         args.n_clips = len(names)
     common = dict(n_layers=args.n_layers, num_heads=args.num_heads, d_model=args.d_model, dim_feedforward=args.dim_feedforward,
@@ -112,14 +113,23 @@ def main(argv=None):
     lo, hi = vdist.shard_bounds(args.n_clips, rank, world)
     streams = [torch.cuda.current_stream(device)]
     f = {k: torch.from_numpy(v[lo:hi]).to(device) for k, v in feats.items()}
-    prim = torch.tensor([default_primer(k) for k in feats["key"][lo:hi, 0]], device=device)
+    # primer (chord, root, attr) rows per clip, (n_local, P, 3): generate.py:246-344
+    if args.primer:                                    # custom chords, typed the user's way ("C Am Dm G")
+        rows = C.primer_from_user_chords(args.primer.replace(",", " ").split())
+        prim = torch.tensor([rows] * (hi - lo), device=device).reshape(hi - lo, len(rows), 3)
+    elif args.primer_from_dataset:                     # the clip's own first chords (:367-379)
+        if args.synthetic:
+            raise SystemExit("--primer_from_dataset needs chord files: use -dataset_dir / --test_ids")
+        prim = torch.from_numpy(own_chords[lo:hi, :args.num_prime_chord]).to(device)
+    else:                                              # "C" for a major key, "A:min" for a minor one (:246-284)
+        prim = torch.tensor([[default_primer(k)] for k in feats["key"][lo:hi, 0]], device=device).reshape(hi - lo, 1, 3)
     with torch.set_grad_enabled(False):
         if args.beam > 1:
             assert False, "No Beam sampling method implemented yet..."     # generate.py:347-349
         print("RAND DIST" if args.beam == 0 else "BEAM: 1")
         if args.music_gen_version is None:
             toks = model.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"],
-                                        prim[:, 0:1], prim[:, 1:2], prim[:, 2:3],
+                                        prim[:, :, 0].contiguous(), prim[:, :, 1].contiguous(), prim[:, :, 2].contiguous(),
                                         target_seq_length=args.target_seq_length_chord, beam=args.beam,
                                         max_conseq_N=max_conseq_N, max_conseq_chord=max_conseq_chord, sampler=args.sampler)
         else:
@@ -130,7 +140,7 @@ def main(argv=None):
                 sl = slice(i, i + 1)
                 with torch.cuda.stream(streams[i % len(streams)]):
                     out = model.generate(f["semantic"][sl], f["key"][i], f["scene_offset"][sl], f["motion"][sl], f["emotion"][sl],
-                                         prim[i, 0:1], prim[i, 1:2], prim[i, 2:3], target_seq_length=args.target_seq_length_chord,
+                                         prim[i, :, 0], prim[i, :, 1], prim[i, :, 2], target_seq_length=args.target_seq_length_chord,
                                          beam=args.beam, max_conseq_N=max_conseq_N, max_conseq_chord=max_conseq_chord,
                                          sampler=args.sampler, use_graph=use_graph)
                     torch.cuda.current_stream().synchronize()

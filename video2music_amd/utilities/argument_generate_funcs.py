@@ -46,6 +46,11 @@ def parse_generate_args(argv=None):
     parser.add_argument("--test_ids", type=str, default=None,
                         help="clip ids to read from -dataset_dir, comma separated, or split:<name> for vevo_meta/split/v1/<name>.txt "
                              "(the reference hard-codes one test_id at generate.py:29)")
+    parser.add_argument("--primer", type=str, default=None,
+                        help='custom primer chords as a user types them, e.g. "C Am Dm G" (the reference edits isPrimer / custumPrimer '
+                             'in generate.py:46-53 for this); default: "C" or "A:min" by the clip\'s key')
+    parser.add_argument("--primer_from_dataset", action="store_true",
+                        help="prime with the clip's own first -num_prime_chord chords (generate.py:367-379: isPrimer with an empty custumPrimer)")
     parser.add_argument("--synthetic_weights", action="store_true", help="random-init procedural weights with real feature files")
     parser.add_argument("--regression", action="store_true",
                         help="also run the VideoRegression head and write <id>_loudness_density.csv (generate.py:394-409)")

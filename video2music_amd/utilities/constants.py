@@ -74,3 +74,27 @@ def primer_from_name(name: str):
     if len(parts) == 1:
         return cid, CHORD_ROOT_DIC[parts[0]], 0
     return cid, CHORD_ROOT_DIC[parts[0]], CHORD_ATTR_DIC[parts[1]]
+
+
+FLAT_TO_SHARP = {"Db": "C#", "Eb": "D#", "Gb": "F#", "Ab": "G#", "Bb": "A#"}          # generate.py:57-63
+_SUFFIX = {"m": "min", "m6": "min6", "m7": "min7", "M6": "maj6", "M7": "maj7"}
+
+
+def normalise_user_chord(name: str) -> str:
+    """A chord as a user types it ("Am", "Bbm7", "F#", "CM7") -> the vocabulary's spelling ("A:min", "A#:min7", "F#",
+    "C:maj7"), by the rules of generate.py:291-312: flats become sharps, the quality is split off after the root, the five
+    short qualities are expanded, an empty quality leaves the bare root; anything else passes through ("Cdim" -> "C:dim")."""
+    p = name
+    if len(p) > 1:
+        if p[1] == "b":
+            p = FLAT_TO_SHARP[p[0:2]] + p[2:]
+        t = 2 if p[1] == "#" else 1
+        root, q = p[:t], p[t:]
+        q = _SUFFIX.get(q, q)
+        p = root if q == "" else root + ":" + q
+    return p
+
+
+def primer_from_user_chords(names):
+    """[(chord, root, attr)] of a custom primer (generate.py:286-329)."""
+    return [primer_from_name(normalise_user_chord(n)) for n in names]
