@@ -249,6 +249,15 @@ int64_t amt_v2_step_ws_floats(int32_t E, int32_t dff, int32_t n_exp);
 int32_t amt_v2_step(const void* const* tab, int32_t n_layers, int32_t H, int32_t E, int32_t dff, int32_t n_exp,
                     int32_t S, int32_t max_seq, int32_t t, int32_t root, int32_t attr, float key, const int32_t* state_dev,
                     float* logits_out, float* ws, void* stream);
+/* The same step for B independent clips in lockstep (all at one position): projections are one launch over B rows (weights
+ * read once per step, not once per clip), the caches carry a leading clip dimension (self K/V: B, H, max_seq, hd; cross K/V:
+ * B, H, S, hd), a mixture layer evaluates all experts on all rows and combines each row's routed pair in expert-index
+ * order.  Same pointer table.  keys_dev: B floats; state_dev: int32 {position, root[B], attr[B]} in device memory, the
+ * position is incremented at the end; logits_out (B, 159); ws: amt_v2_step_batch_ws_floats(E, dff, n_exp, B) floats. */
+int64_t amt_v2_step_batch_ws_floats(int32_t E, int32_t dff, int32_t n_exp, int32_t B);
+int32_t amt_v2_step_batch(const void* const* tab, int32_t n_layers, int32_t H, int32_t E, int32_t dff, int32_t n_exp,
+                          int32_t S, int32_t max_seq, int32_t B, const float* keys_dev, int32_t* state_dev,
+                          float* logits_out, float* ws, void* stream);
 
 /* ---- regression head VideoRegression(regModel='bimamba+') (model/video_regression.py:104-245) ---- */
 /* Depthwise causal Conv1d(kernel K, padding K-1)[..., :L] + SiLU of MambaBlock.forward (mamba.py:172-175,268-272):

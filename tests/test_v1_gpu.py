@@ -74,7 +74,44 @@ def test_cli_runs_the_other_families(tmp_path, version):
     from video2music_amd import generate as G
     base = ["--synthetic", "--n_clips", "3", "-n_layers", "4", "-num_heads", "4", "-d_model", "128", "-dim_feedforward", "256",
             "-target_seq_length_chord", "24", "--sampler", "argmax", "-music_gen_version", version]
-    a = G.main(base + ["-output_dir", str(tmp_path / "a"), "--v2_streams", "1"]).cpu()
-    b = G.main(base + ["-output_dir", str(tmp_path / "b"), "--v2_streams", "2"]).cpu()
+    a = G.main(base + ["-output_dir", str(tmp_path / "a"), "--v2_batch", "1"]).cpu()
+    b = G.main(base + ["-output_dir", str(tmp_path / "b"), "--v2_batch", "2"]).cpu()
     assert a.shape == (3, 24) and torch.equal(a, b)
     assert (tmp_path / "a" / "clip000_chords.lab").exists()
+
+
+def _v2(version, **over):
+    from video2music_amd.model.video_music_transformer import VideoMusicTransformer_V2
+    from tests.helpers import CFG_V2
+    m = VideoMusicTransformer_V2(**dict(CFG_V2, version_name=version, **over)).eval()
+    shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=0).items()}, strict=False)
+    return m.cuda()
+
+
+@pytest.mark.parametrize("make,B,P", [(lambda: _v2("2.2"), 5, 1), (lambda: _v2("2.0"), 3, 3), (lambda: _v2("2.2", chord_embed=True), 2, 1),
+                                      (lambda: build("1.0"), 4, 1), (lambda: build("1.1", True), 3, 2), (lambda: build("1.2"), 2, 1)])
+def test_lockstep_generate_batch_equals_per_clip_generate(make, B, P):
+    """generate_batch (B clips through one captured lockstep step, all experts evaluated on all rows) gives, clip by clip,
+    the ids of `generate` on that clip alone -- greedy and top-1 branches, shared and per-clip primers."""
+    m = make()
+    T = 36
+    f = {k: v.cuda() for k, v in feats_t(synthetic.synthetic_features(B, seed=77)).items()}
+    rs = np.random.RandomState(B)
+    ids = torch.from_numpy(rs.randint(1, 157, size=(B, P)))
+    from video2music_amd.utilities.constants import chord_to_root_attr
+    ra = torch.tensor([[chord_to_root_attr(int(i)) for i in row] for row in ids])
+    pr = (ids, ra[:, :, 0], ra[:, :, 1])
+    args = (f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"])
+    with torch.no_grad():
+        for kw in (dict(beam=0, sampler="argmax"), dict(beam=1), dict(beam=0, sampler="argmax", temperature=0.8, max_conseq_N=1, max_conseq_chord=3)):
+            got = m.generate_batch(*args, *pr, target_seq_length=T, **kw)
+            assert got.shape == (B, T)
+            for c in range(B):
+                one = m.generate(f["semantic"][c:c + 1], f["key"][c], f["scene_offset"][c:c + 1], f["motion"][c:c + 1], f["emotion"][c:c + 1],
+                                 pr[0][c], pr[1][c], pr[2][c], target_seq_length=T, **kw)
+                assert torch.equal(one[0], got[c]), (kw, c)
+        eager = m.generate_batch(*args, *pr, target_seq_length=T, beam=0, sampler="argmax", use_graph=False)
+        assert torch.equal(eager, m.generate_batch(*args, *pr, target_seq_length=T, beam=0, sampler="argmax"))
+        rnd = m.generate_batch(*args, pr[0][0], pr[1][0], pr[2][0], target_seq_length=T, beam=0)       # shared primer, random draw
+        assert rnd.shape == (B, T) and int(rnd[:, P:].min()) >= 1 and int(rnd.max()) < 157

@@ -96,13 +96,13 @@ def test_v2_cached_decode_equals_per_step_reforward(v2):
 
 
 def test_cli_decodes_several_v2_clips_concurrently(tmp_path):
-    """`python -m video2music_amd.generate` with the default V2 model: clips decoded on several streams / host threads give
-    the ids of the one-at-a-time run."""
+    """`python -m video2music_amd.generate` with the default V2 model: clips decoded together in lockstep give the ids of the
+    one-at-a-time run."""
     from video2music_amd import generate as G
     base = ["--synthetic", "--n_clips", "6", "-n_layers", "4", "-num_heads", "4", "-d_model", "128", "-dim_feedforward", "256",
             "-target_seq_length_chord", "40", "--sampler", "argmax", "-music_gen_version", "2.2"]
-    a = G.main(base + ["-output_dir", str(tmp_path / "a"), "--v2_streams", "1"]).cpu()
-    b = G.main(base + ["-output_dir", str(tmp_path / "b"), "--v2_streams", "4"]).cpu()
+    a = G.main(base + ["-output_dir", str(tmp_path / "a"), "--v2_batch", "1"]).cpu()
+    b = G.main(base + ["-output_dir", str(tmp_path / "b"), "--v2_batch", "4"]).cpu()
     assert a.shape == (6, 40) and torch.equal(a, b)
 
 

@@ -21,5 +21,15 @@ with torch.no_grad():
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(3): m(root, root, attr, f8["semantic"], f8["key"], f8["scene_offset"], f8["motion"], f8["emotion"])
     torch.cuda.synchronize(); df = (time.perf_counter() - t0) / 3
+    batch = {}
+    for nb in (4, 16, 32):                   # lockstep generate_batch: clips per second and per-step time
+        fb = {k: torch.from_numpy(v).cuda() for k, v in synthetic.synthetic_features(nb, seed=5).items()}
+        args = (fb["semantic"], fb["key"], fb["scene_offset"], fb["motion"], fb["emotion"], kw["primer"], kw["primer_root"], kw["primer_attr"])
+        m.generate_batch(*args, target_seq_length=8, beam=0, sampler="argmax")
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ob = m.generate_batch(*args, target_seq_length=300, beam=0, sampler="argmax")
+        torch.cuda.synchronize(); db = time.perf_counter() - t0
+        batch[f"B{nb}"] = {"s": round(db, 3), "tokens_per_s": round(nb * 299 / db, 1), "ms_per_step": round(db / 299 * 1e3, 3)}
 print(json.dumps({"v2_generate_T300_s": round(dt, 3), "tokens_per_s": round(299 / dt, 1), "unique_ids": len(set(out.flatten().tolist())),
-                  "v2_forward_B8_L300_ms": round(df * 1e3, 2)}))
+                  "v2_forward_B8_L300_ms": round(df * 1e3, 2),
+                  "v2_generate_batch_T300": batch}))

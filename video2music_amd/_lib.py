@@ -75,9 +75,11 @@ SIGNATURES = {
     "amt_v2_step_ws_floats": [_I, _I, _I],
     "amt_pack_weight_fwd": [_P, _P, _I, _I, _P],
     "amt_v2_step": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P],
+    "amt_v2_step_batch_ws_floats": [_I, _I, _I, _I],
+    "amt_v2_step_batch": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
 }
 _RESTYPES = {"amt_last_error": C.c_char_p, "amt_decode_step_bytes": C.c_int64, "amt_moe_scratch_floats": C.c_int64,
-             "amt_v2_step_ws_floats": C.c_int64}
+             "amt_v2_step_ws_floats": C.c_int64, "amt_v2_step_batch_ws_floats": C.c_int64}
 _NO_STATUS = set(_RESTYPES) | {"amt_abi_version"}
 
 _lib = None

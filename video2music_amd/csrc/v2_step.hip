@@ -196,3 +196,171 @@ extern "C" int32_t amt_v2_step(const void* const* tab, int32_t n_layers, int32_t
     if (pos) { hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, s, (int*)state_dev); AMT_LAUNCH_CHECK(); }
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The same step for B independent clips in lockstep (all at the same position): every projection is one skinny-GEMM launch
+// over B rows -- the weights are read once per step instead of once per clip --, the attentions run the decode kernel with
+// a clip dimension, and a mixture layer evaluates all its experts on all rows (at B >= 3 every expert's weights are read
+// anyway; 3x the flops of the routed pair is nothing at these sizes) and combines each row's two in expert-index order.
+// ------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+// state {position, root[B], attr[B]} in device memory; keys[B]
+__global__ void embed_rows_kernel(const int* __restrict__ state, int B, const float* __restrict__ keys, const float* __restrict__ PR,
+                                  const float* __restrict__ PA, const float* __restrict__ wkey, const float* __restrict__ bias,
+                                  float* __restrict__ out, int d, const float* __restrict__ pe) {
+    const int b = blockIdx.x;
+    const int t = state[0], root = state[1 + b], attr = state[1 + B + b];
+    const float kv = keys[b];
+    if (pe) pe += (size_t)t * d;
+    for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
+        const float4 pr = ld4(PR + (size_t)root * d + c), pa = ld4(PA + (size_t)attr * d + c);
+        const float4 wk = ld4(wkey + c), bb = ld4(bias + c);
+        const float4 pp = pe ? ld4(pe + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 o;        // the summation order of embed_one_kernel
+        o.x = ((pr.x + pa.x) + kv * wk.x + bb.x) + pp.x; o.y = ((pr.y + pa.y) + kv * wk.y + bb.y) + pp.y;
+        o.z = ((pr.z + pa.z) + kv * wk.z + bb.z) + pp.z; o.w = ((pr.w + pa.w) + kv * wk.w + bb.w) + pp.w;
+        st4(out + (size_t)b * d + c, o);
+    }
+}
+
+// rope_place_kernel over B rows: x row b at x + b*ldx; dst row b contiguous [B][E] or clip b of a [B][H][cap][hd] cache
+__global__ void rope_place_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ rope, float* __restrict__ dst,
+                                       float scale, int E, int hd, int cap, const int* __restrict__ pos, int head_major) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (2 * i >= E) return;
+    const int t = *pos;
+    x += (size_t)b * ldx;
+    const float x0 = x[2 * i], x1 = x[2 * i + 1];
+    float y0 = x0, y1 = x1;
+    if (rope) {
+        const float c = rope[(size_t)t * E + 2 * i], sn = rope[(size_t)t * E + 2 * i + 1];
+        y0 = x0 * c - x1 * sn;
+        y1 = x1 * c + x0 * sn;
+    }
+    const int e = 2 * i, h = e / hd, cc = e - h * hd;
+    float* o = head_major ? dst + (((size_t)b * (E / hd) + h) * cap + t) * hd + cc : dst + (size_t)b * E + e;
+    o[0] = y0 * scale;
+    o[1] = y1 * scale;
+}
+
+// row of expert e's output for clip b inside Y[n_exp][B][E]
+__global__ void dense_slot_kernel(const int* __restrict__ idx, int* __restrict__ slot_pos, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * B) slot_pos[i] = idx[i] * B + (i >> 1);
+}
+
+int32_t lin_rows(const float* x, const float* wp, const float* b, const float* resid, float* y, int B, int N, int K, hipStream_t s) {
+    DecodeGemmParams g{};
+    g.B = B; g.eps = 1e-5f; g.scale = 1.f; g.x = x; g.ldx = K; g.Wp = wp; g.bias = b; g.N = N; g.K = K;
+    g.resid = resid; g.ldr = N; g.y = y; g.ldy = N;
+    return amt_launch_decode_gemm(g, s);
+}
+
+int32_t norm_rows(const float* x, const float* resid, const float* w, const float* b, float* y, int B, int E, hipStream_t s) {
+    if (b) return amt_launch_layernorm(x, resid, w, b, nullptr, nullptr, y, B, E, 1e-5f, s);
+    return amt_launch_rmsnorm(x, w, y, B, E, 1e-6f, s, resid);
+}
+
+int32_t place_rows(const float* x, int ldx, const float* rope, float* dst, float scale, int B, int E, int hd, int cap, const int* pos,
+                   int head_major, hipStream_t s) {
+    hipLaunchKernelGGL(rope_place_rows_kernel, dim3(cdiv(E / 2, 256), B), dim3(256), 0, s, x, ldx, rope, dst, scale, E, hd, cap, pos, head_major);
+    AMT_LAUNCH_CHECK();
+    return 0;
+}
+
+int32_t attn_rows(const float* q, const float* k, const float* v, float* o, int B, int H, int hd, int cap, int n_keys, const int* pos,
+                  hipStream_t s) {
+    AttnDecodeParams a{};
+    a.q = q; a.k = k; a.v = v; a.o = o; a.B = B; a.H = H; a.hd = hd; a.cap = cap; a.n_keys = n_keys; a.pos = pos;
+    return amt_launch_attn_decode(a, s);
+}
+
+// expert on B rows; scratch 3*B*dff floats
+int32_t glu_rows(const float* x, const float* w1, const float* b1, const float* wg, const float* bg, const float* w2, const float* b2,
+                 float* y, float* scratch, int B, int E, int dff, hipStream_t s) {
+    float* g = scratch; float* u = g + (size_t)B * dff; float* hh = u + (size_t)B * dff;
+    int32_t rc;
+    if ((rc = lin_rows(x, wg, bg, nullptr, g, B, dff, E, s))) return rc;
+    if (w1 && (rc = lin_rows(x, w1, b1, nullptr, u, B, dff, E, s))) return rc;
+    hipLaunchKernelGGL(glu_mul_kernel, dim3(cdiv(B * dff, 1024)), dim3(256), 0, s, w1 ? u : nullptr, g, hh, B * dff);
+    AMT_LAUNCH_CHECK();
+    return lin_rows(hh, w2, b2, nullptr, y, B, E, dff, s);
+}
+
+}  // namespace
+
+extern "C" int64_t amt_v2_step_batch_ws_floats(int32_t E, int32_t dff, int32_t n_exp, int32_t B) {
+    return (int64_t)B * ((int64_t)(9 + n_exp) * E + 3 * dff + 8) + 64;
+}
+
+extern "C" int32_t amt_v2_step_batch(const void* const* tab, int32_t n_layers, int32_t H, int32_t E, int32_t dff, int32_t n_exp,
+                                     int32_t S, int32_t max_seq, int32_t B, const float* keys_dev, int32_t* state_dev,
+                                     float* logits_out, float* ws, void* stream) {
+    AMT_CHECK_ARG(tab && logits_out && ws && keys_dev && state_dev, "amt_v2_step_batch: null pointer");
+    AMT_CHECK_ARG(n_layers > 0 && H > 0 && E % H == 0 && E % 64 == 0 && dff % 64 == 0 && E <= 1536 && dff <= 1536 && S > 0 && max_seq > 0,
+                  "amt_v2_step_batch: bad shape (E and dff must be multiples of 64, at most 1536)");
+    AMT_CHECK_ARG(B >= 1 && B <= 256 && n_exp >= 0 && n_exp <= 64, "amt_v2_step_batch: 1..256 clips, at most 64 experts");
+    hipStream_t s = (hipStream_t)stream;
+    const int hd = E / H;
+    const float qscale = 1.0f / sqrtf((float)hd);
+    auto G = [&](int i) { return (const float*)tab[i]; };
+    const size_t BE = (size_t)B * E;
+    float* x = ws; float* y = x + BE; float* qkv = y + BE; float* q = qkv + 3 * BE; float* o = q + BE; float* u = o + BE;
+    float* ysh = u + BE;                                  // shared expert output [B][E]
+    float* Yall = ysh + BE;                               // every expert's output [n_exp][B][E]
+    float* ffs = Yall + (size_t)n_exp * BE;               // 3*B*dff expert scratch
+    float* moe_w = ffs + (size_t)3 * B * dff;             // routing weights [B][2], indices [B][2], rows in Yall [B][2]
+    int32_t* moe_idx = (int32_t*)(moe_w + 2 * B);
+    int32_t* slot_pos = moe_idx + 2 * B;
+    const int* pos = state_dev;
+    int32_t rc;
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(B), dim3(128), 0, s, state_dev, B, keys_dev, G(G_PR), G(G_PA), G(G_WKEY), G(G_CBIAS), x, E, G(G_PE));
+    AMT_LAUNCH_CHECK();
+    const float* rope = G(G_ROPE);
+    for (int l = 0; l < n_layers; ++l) {
+        const void* const* L = tab + G_PTRS + (size_t)l * L_PTRS;
+        auto P = [&](int i) { return (const float*)L[i]; };
+        float* kc = (float*)L[L_KC]; float* vc = (float*)L[L_VC];                 // [B][H][max_seq][hd]
+        if ((rc = lin_rows(x, P(L_SAW), P(L_SAB), nullptr, qkv, B, 3 * E, E, s))) return rc;
+        if ((rc = place_rows(qkv, 3 * E, rope, q, qscale, B, E, hd, 0, pos, 0, s))) return rc;
+        if ((rc = place_rows(qkv + E, 3 * E, rope, kc, 1.f, B, E, hd, max_seq, pos, 1, s))) return rc;
+        if ((rc = place_rows(qkv + 2 * E, 3 * E, nullptr, vc, 1.f, B, E, hd, max_seq, pos, 1, s))) return rc;
+        if ((rc = attn_rows(q, kc, vc, o, B, H, hd, max_seq, 0, pos, s))) return rc;
+        if ((rc = lin_rows(o, P(L_SAOW), P(L_SAOB), x, u, B, E, E, s))) return rc;
+        if ((rc = norm_rows(u, nullptr, P(L_N1W), P(L_N1B), x, B, E, s))) return rc;
+        if ((rc = lin_rows(x, P(L_CAW), P(L_CAB), nullptr, qkv, B, E, E, s))) return rc;
+        if ((rc = place_rows(qkv, E, rope, q, qscale, B, E, hd, 0, pos, 0, s))) return rc;
+        if ((rc = attn_rows(q, P(L_KX), P(L_VX), o, B, H, hd, S, S, nullptr, s))) return rc;      // [B][H][S][hd]
+        if ((rc = lin_rows(o, P(L_CAOW), P(L_CAOB), x, u, B, E, E, s))) return rc;
+        if ((rc = norm_rows(u, nullptr, P(L_N2W), P(L_N2B), x, B, E, s))) return rc;
+        if (!L[L_GATEW]) {
+            if ((rc = glu_rows(x, P(L_W1), P(L_B1), P(L_WG), P(L_BG), P(L_W2), P(L_B2), y, ffs, B, E, dff, s))) return rc;
+        } else {
+            if ((rc = amt_moe_route_fwd(x, P(L_GATEW), P(L_GATEB), moe_idx, moe_w, B, E, n_exp, s))) return rc;
+            const size_t pw1 = (size_t)dff * E, pw2 = (size_t)((E + 15) / 16 * 16) * dff;       // packed sizes per expert
+            for (int e = 0; e < n_exp; ++e) {
+                const float* w1 = P(L_W1) ? P(L_W1) + e * pw1 : nullptr;
+                const float* b1 = P(L_B1) ? P(L_B1) + (size_t)e * dff : nullptr;
+                if ((rc = glu_rows(x, w1, b1, P(L_WG) + e * pw1, P(L_BG) + (size_t)e * dff, P(L_W2) + e * pw2, P(L_B2) + (size_t)e * E,
+                                   Yall + e * BE, ffs, B, E, dff, s))) return rc;
+            }
+            hipLaunchKernelGGL(dense_slot_kernel, dim3(cdiv(2 * B, 256)), dim3(256), 0, s, moe_idx, slot_pos, B);
+            AMT_LAUNCH_CHECK();
+            const float* shared = nullptr;
+            if (L[L_SWG]) {
+                if ((rc = glu_rows(x, P(L_SW1), P(L_SB1), P(L_SWG), P(L_SBG), P(L_SW2), P(L_SB2), ysh, ffs, B, E, dff, s))) return rc;
+                shared = ysh;
+            }
+            if ((rc = amt_moe_combine_fwd(Yall, slot_pos, moe_idx, moe_w, shared, 0.5f, y, B, E, s))) return rc;
+        }
+        if ((rc = norm_rows(y, x, P(L_N3W), P(L_N3B), u, B, E, s))) return rc;
+        float* tmp = x; x = u; u = tmp;
+    }
+    if ((rc = norm_rows(x, nullptr, G(G_FNW), G(G_FNB), y, B, E, s))) return rc;
+    if ((rc = lin_rows(y, G(G_WOUT), G(G_BOUT), nullptr, logits_out, B, 159, E, s))) return rc;
+    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, s, state_dev);
+    AMT_LAUNCH_CHECK();
+    return 0;
+}
+

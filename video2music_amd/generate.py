@@ -111,7 +111,6 @@ def main(argv=None):
         model.load_state_dict(torch.load(args.model_weights, map_location="cpu"))
     model = model.to(device).eval()
     lo, hi = vdist.shard_bounds(args.n_clips, rank, world)
-    streams = [torch.cuda.current_stream(device)]
     f = {k: torch.from_numpy(v[lo:hi]).to(device) for k, v in feats.items()}
     # primer (chord, root, attr) rows per clip, (n_local, P, 3): generate.py:246-344
     if args.primer:                                    # custom chords, typed the user's way ("C Am Dm G")
@@ -133,31 +132,17 @@ def main(argv=None):
                                         target_seq_length=args.target_seq_length_chord, beam=args.beam,
                                         max_conseq_N=max_conseq_N, max_conseq_chord=max_conseq_chord, sampler=args.sampler)
         else:
-            # V2 generates one clip at a time like the reference (its RoPE view ties a batch together); each clip's
-            # decode is a latency-bound chain of small launches, so several clips run concurrently, one HIP stream and
-            # one host thread each (the per-token library call releases the GIL)
-            def one(i, use_graph=False):
-                sl = slice(i, i + 1)
-                with torch.cuda.stream(streams[i % len(streams)]):
-                    out = model.generate(f["semantic"][sl], f["key"][i], f["scene_offset"][sl], f["motion"][sl], f["emotion"][sl],
-                                         prim[i, :, 0], prim[i, :, 1], prim[i, :, 2], target_seq_length=args.target_seq_length_chord,
-                                         beam=args.beam, max_conseq_N=max_conseq_N, max_conseq_chord=max_conseq_chord,
-                                         sampler=args.sampler, use_graph=use_graph)
-                    torch.cuda.current_stream().synchronize()
-                return out
+            # the V1 / V2 / V3 classes generate one clip per call in the reference; here the clips of this rank advance in
+            # lockstep through one captured step graph, --v2_batch clips at a time (each projection then reads its weights
+            # once per step for all of them); per clip the ids equal the one-clip generate
             n_local = hi - lo
             rows = []
-            if n_local:
-                rows.append(one(0, True))              # first clip alone: builds the derived tables and packed weights once
-                workers = max(1, min(args.v2_streams, n_local - 1))
-                streams = [torch.cuda.Stream(device=device) for _ in range(workers)]
-                torch.cuda.synchronize(device)
-                if n_local > 1 and workers == 1:        # one at a time: each clip replays a captured step graph
-                    rows += [one(i, True) for i in range(1, n_local)]
-                elif n_local > 1:                      # concurrent clips issue their steps eagerly (no capture across threads)
-                    from concurrent.futures import ThreadPoolExecutor
-                    with ThreadPoolExecutor(max_workers=workers) as pool:
-                        rows += list(pool.map(one, range(1, n_local)))
+            for c0 in range(0, n_local, max(1, args.v2_batch)):
+                sl = slice(c0, min(n_local, c0 + max(1, args.v2_batch)))
+                rows.append(model.generate_batch(f["semantic"][sl], f["key"][sl], f["scene_offset"][sl], f["motion"][sl], f["emotion"][sl],
+                                                 prim[sl, :, 0], prim[sl, :, 1], prim[sl, :, 2],
+                                                 target_seq_length=args.target_seq_length_chord, beam=args.beam, max_conseq_N=max_conseq_N,
+                                                 max_conseq_chord=max_conseq_chord, sampler=args.sampler))
             toks = torch.cat(rows) if rows else torch.empty(0, args.target_seq_length_chord, dtype=torch.long, device=device)
         toks = vdist.all_gather_sequences(toks, args.n_clips)
         reg_rows = None

@@ -633,19 +633,28 @@ class VideoMusicTransformer_V2(nn.Module):
     # positions never change: the decoder can run one token at a time over cached keys/values.  Every kernel computes
     # its rows independently and in the same order as in the full forward, so the step's logits equal row t of `_decode`.
     def _cache_init(self, memory, S):
+        """`memory`: one clip's encoder output (S, E), or a list of them for the lockstep step of several clips
+        (`generate_batch`: every cache then carries a leading clip dimension)."""
         from .. import ops
         E, H = self.d_model, self.nhead
         hd = E // H
-        dev = memory.device
-        st = {"cross": [], "self": [], "S": S}
+        mems = list(memory) if isinstance(memory, (list, tuple)) else [memory]
+        nb = len(mems)
+        dev = mems[0].device
+        st = {"cross": [], "self": [], "S": S, "B": nb}
+        rows = mems[0] if nb == 1 else torch.cat(mems)                  # (nb*S, E): one projection launch for all clips
+        cross_all = []
         for lyr in self.transformer.decoder.layers:
             a = lyr.cross_attn
             W, b = a.in_proj_weight.detach(), a.in_proj_bias.detach()
-            k = ops.linear(memory, W[E:2 * E], b[E:2 * E])
-            if self._rope_cache is not None:
-                k = ops.rope(k.view(H, S, 1, hd), self._rope_cache).view(S, E)
-            v = ops.linear(memory, W[2 * E:], b[2 * E:])
-            st["cross"].append((k, v))
+            k = ops.linear(rows, W[E:2 * E], b[E:2 * E])
+            if self._rope_cache is not None:                           # per clip: the B = 1 view, positions 0..S-1
+                for c in range(nb):
+                    kc_ = k[c * S:(c + 1) * S]
+                    ops.rope(kc_.view(H, S, 1, hd), self._rope_cache, out=kc_.view(H, S, 1, hd))
+            v = ops.linear(rows, W[2 * E:], b[2 * E:])
+            cross_all.append((k, v))
+            st["cross"].append((k[:S], v[:S]))
             st["self"].append((torch.empty(self._max_dec, E, device=dev), torch.empty(self._max_dec, E, device=dev)))
         # pointer table of amt_v2_step (include/amt_hip.h); `keep` holds every tensor the table points into
         keep, ptrs = [], []
@@ -679,11 +688,11 @@ class VideoMusicTransformer_V2(nn.Module):
                 cache[sig] = torch.cat([packed(l.weight) for l in lins])
             return cache[sig]
 
-        def nb(n):          # a norm's bias; None (RMSNorm) selects the RMS form inside the step
+        def nbias(n):       # a norm's bias; None (RMSNorm) selects the RMS form inside the step
             return getattr(n, "bias", None)
 
         for t in (self._PR, self._PA, self._wkey, self.Linear_chord.bias, self._rope_cache, self.transformer.decoder.norm.weight,
-                  nb(self.transformer.decoder.norm), packed(self.Wout.weight), self.Wout.bias,
+                  nbias(self.transformer.decoder.norm), packed(self.Wout.weight), self.Wout.bias,
                   torch.tensor([0, 1], device=dev, dtype=torch.int32), self._pe_chord if self._learned_pos else None):
             add(t)
         from .moe import GLUExpert, SiLUExpert, _stack, expert_dff, expert_parts
@@ -697,15 +706,15 @@ class VideoMusicTransformer_V2(nn.Module):
                 add(None if q[name] is None else q[name].bias)
 
         # the one-call step streams K/V with the decode-attention kernel: head-major caches (H, rows, hd)
-        st["self_hm"] = [(torch.empty(H, self._max_dec, hd, device=dev), torch.empty(H, self._max_dec, hd, device=dev))
+        st["self_hm"] = [(torch.empty(nb, H, self._max_dec, hd, device=dev), torch.empty(nb, H, self._max_dec, hd, device=dev))
                          for _ in st["self"]]
-        st["cross_hm"] = [(k.view(S, H, hd).permute(1, 0, 2).contiguous(), v.view(S, H, hd).permute(1, 0, 2).contiguous())
-                          for k, v in st["cross"]]
+        st["cross_hm"] = [(k.view(nb, S, H, hd).permute(0, 2, 1, 3).contiguous(), v.view(nb, S, H, hd).permute(0, 2, 1, 3).contiguous())
+                          for k, v in cross_all]
         for lyr, (kc, vc), (kx, vx) in zip(self.transformer.decoder.layers, st["self_hm"], st["cross_hm"]):
             sa, ca = lyr.self_attn, lyr.cross_attn
-            for t in (packed(sa.in_proj_weight), sa.in_proj_bias, packed(sa.out_proj.weight), sa.out_proj.bias, lyr.norm1.weight, nb(lyr.norm1),
+            for t in (packed(sa.in_proj_weight), sa.in_proj_bias, packed(sa.out_proj.weight), sa.out_proj.bias, lyr.norm1.weight, nbias(lyr.norm1),
                       packed(ca.in_proj_weight, rows=E), ca.in_proj_bias, packed(ca.out_proj.weight), ca.out_proj.bias, lyr.norm2.weight,
-                      nb(lyr.norm2), lyr.norm3.weight, nb(lyr.norm3), kc, vc, kx, vx):
+                      nbias(lyr.norm2), lyr.norm3.weight, nbias(lyr.norm3), kc, vc, kx, vx):
                 add(t)
             ff = lyr.ff
             if isinstance(ff, (GLUExpert, SiLUExpert)):
@@ -738,8 +747,10 @@ class VideoMusicTransformer_V2(nn.Module):
         # amt_v2_step lays its scratch out for one feed-forward width; layers of different widths (V1 '1.3.3' / '1.3.4' with
         # dim_feedforward != 2 d_model) take the same cached step issued operator by operator (`_decode_step`)
         st["native"] = len(widths) == 1
-        st["ws"] = torch.empty(_lib.call("amt_v2_step_ws_floats", E, dff, self.n_experts), device=dev, dtype=torch.float32)
-        st["logits"] = torch.empty(CHORD_SIZE, device=dev, dtype=torch.float32)
+        n_ws = (_lib.call("amt_v2_step_ws_floats", E, dff, self.n_experts) if nb == 1
+                else _lib.call("amt_v2_step_batch_ws_floats", E, dff, self.n_experts, nb))
+        st["ws"] = torch.empty(n_ws, device=dev, dtype=torch.float32)
+        st["logits"] = torch.empty(CHORD_SIZE, device=dev, dtype=torch.float32) if nb == 1 else torch.empty(nb, CHORD_SIZE, device=dev)
         return st
 
     def _decode_step_native(self, root, attr, key, t, st, state=None):
@@ -814,6 +825,96 @@ class VideoMusicTransformer_V2(nn.Module):
         if self.chord_embed:                     # the chord ids themselves index the frozen table (:431-432)
             x_root, x_attr = x, torch.zeros_like(x)
         return self._decode(x_root, x_attr, feature_key, memory, B, S)
+
+    def _step_batch(self, st, keys, state):
+        _lib.call("amt_v2_step_batch", st["tab"], self.nlayers, self.nhead, self.d_model, st["dff"], self.n_experts, st["S"],
+                  self._max_dec, st["B"], _lib.ptr(keys), _lib.ptr(state), _lib.ptr(st["logits"]), _lib.ptr(st["ws"]), _lib.stream_ptr())
+
+    def generate_batch(self, feature_semantic_list, feature_key, feature_scene_offset, feature_motion, feature_emotion,
+                       primer, primer_root, primer_attr, target_seq_length=300, beam=0, beam_chance=1.0, max_conseq_N=0,
+                       max_conseq_chord=2, temperature=1.0, sampler="categorical", use_graph=True):
+        """`generate` for B clips at once -> LongTensor (B, T); row b equals `generate` on clip b alone (the reference
+        generates one clip per call).  Features (B, S, .), key (B,) / (B, 1); primers (P,) shared or (B, P).
+
+        The clips advance in lockstep through one captured step graph (`amt_v2_step_batch`): each projection reads its
+        weights once per step for all clips.  The video encoder runs per clip (for B > 1 the reference's raw RoPE view
+        would tie the clips of a batch together); the per-step decision runs on the host as in `generate`."""
+        from ..utilities.constants import chord_to_root_attr
+        assert (not self.training), "Cannot generate while in training mode"
+        if beam not in (0, 1):
+            raise NotImplementedError("beam > 1 is not implemented (generate.py:347-349 asserts it out as well)")
+        dev = self.Wout.weight.device
+        T = int(target_seq_length)
+        if T > self._max_dec:
+            raise ValueError(f"chord sequence longer than the positional table ({self._max_dec}), like in the reference")
+        nb = feature_semantic_list.shape[0]
+        prim = [torch.as_tensor(q).long().cpu() for q in (primer, primer_root, primer_attr)]
+        prim = [q.unsqueeze(0).expand(nb, -1) if q.dim() == 1 else q for q in prim]
+        P = prim[0].shape[1]
+        gen = torch.full((nb, T), CHORD_PAD, dtype=torch.long)
+        gen_root = torch.full((nb, T), CHORD_ROOT_PAD, dtype=torch.long)
+        gen_attr = torch.full((nb, T), CHORD_ATTR_PAD, dtype=torch.long)
+        gen[:, :P], gen_root[:, :P], gen_attr[:, :P] = prim
+        if self.chord_embed:
+            gen_root[:, :P], gen_attr[:, :] = gen[:, :P], 0
+        key = feature_key.to(dtype=torch.float32).reshape(-1)
+        key = (key.expand(nb) if key.numel() == 1 else key).contiguous()
+        mems, S = [], None
+        for c in range(nb):
+            sl = slice(c, c + 1)
+            m, _, S = self._encode_memory(feature_semantic_list[sl], feature_scene_offset[sl], feature_motion[sl], feature_emotion[sl])
+            mems.append(m)
+        st = self._cache_init(mems, S)
+        if nb == 1 or not st["native"]:            # one clip, or layers of unequal width: the single-clip loop
+            rows = [self.generate(feature_semantic_list[c:c + 1], key[c], feature_scene_offset[c:c + 1], feature_motion[c:c + 1],
+                                  feature_emotion[c:c + 1], prim[0][c], prim[1][c], prim[2][c], target_seq_length=T, beam=beam,
+                                  beam_chance=beam_chance, max_conseq_N=max_conseq_N, max_conseq_chord=max_conseq_chord,
+                                  temperature=temperature, sampler=sampler, use_graph=use_graph) for c in range(nb)]
+            return torch.cat(rows)
+        keys = key.to(dev)
+        state = torch.zeros(1 + 2 * nb, dtype=torch.int32, device=dev)
+        ra_table = torch.tensor([chord_to_root_attr(i) for i in range(CHORD_END)])          # id -> (root, attr) feedback (:578-597)
+
+        def feed(t):
+            state[1:] = torch.cat((gen_root[:, t], gen_attr[:, t])).to(torch.int32)
+
+        feed(0)
+        self._step_batch(st, keys, state)                               # position 0, eagerly (the warm-up a capture needs)
+        graph = None
+        if use_graph and T > 2:
+            torch.cuda.current_stream().synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with _CAPTURE_LOCK, torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                self._step_batch(st, keys, state)
+        for cur in range(1, T):
+            if cur - 1 > 0:                                             # logits of input position cur-1
+                feed(cur - 1)
+                graph.replay() if graph is not None else self._step_batch(st, keys, state)
+            if cur < P:
+                continue
+            # row by row, the arithmetic of `generate` (and a (B, 159) CPU softmax would wake torch's whole thread pool)
+            lg = st["logits"].cpu()
+            probs = torch.stack([torch.softmax(row / temperature, dim=-1)[:CHORD_END] for row in lg])
+            if beam == 1:
+                tok = probs.argmax(-1)                                  # topk(., 1) per clip (:547-560); no root/attr feedback
+                gen[:, cur] = tok
+                if self.chord_embed:
+                    gen_root[:, cur] = tok
+                continue
+            if max_conseq_N == 0:
+                probs[:, 0] = 0.0
+            if cur >= max_conseq_chord:
+                same = torch.ones(nb, dtype=torch.bool)
+                for k in range(1, max_conseq_chord):
+                    same &= gen[:, cur - 1] == gen[:, cur - 1 - k]
+                probs[same, gen[same, cur - 1]] = 0.0
+            if sampler == "argmax":
+                tok = (probs / probs.sum(-1, keepdim=True)).argmax(-1)
+            else:
+                tok = torch.distributions.categorical.Categorical(probs=probs).sample()
+            gen[:, cur] = tok
+            gen_root[:, cur], gen_attr[:, cur] = (tok, 0) if self.chord_embed else (ra_table[tok, 0], ra_table[tok, 1])
+        return gen.to(dev)
 
     def generate(self, feature_semantic_list=[], feature_key=None, feature_scene_offset=None, feature_motion=None,
                  feature_emotion=None, primer=None, primer_root=None, primer_attr=None, target_seq_length=300, beam=0,
@@ -1101,6 +1202,18 @@ class VideoMusicTransformer_V3(VideoMusicTransformer_V2):
         t = self._attention(h, h, lyr.self_attn, L, L, B, True, t)
         t = self._attention(self._ln(t, lyr.norm2), memory, lyr.cross_attn, L, S, B, False, t)
         return ops.add(t, self._ff(self._ln(t, lyr.norm3), lyr.ff, L, B))
+
+    def generate_batch(self, feature_semantic_list, feature_key, feature_scene_offset, feature_motion, feature_emotion,
+                       primer, primer_root, primer_attr, **kw):
+        """B clips, one after the other (no cached lockstep step for V3, see the class docstring) -> (B, T)."""
+        kw.pop("use_graph", None)
+        nb = feature_semantic_list.shape[0]
+        key = feature_key.reshape(-1)
+        key = key.expand(nb) if key.numel() == 1 else key
+        pr = [torch.as_tensor(q) for q in (primer, primer_root, primer_attr)]
+        rows = [self.generate(feature_semantic_list[c:c + 1], key[c], feature_scene_offset[c:c + 1], feature_motion[c:c + 1],
+                              feature_emotion[c:c + 1], *[(q if q.dim() == 1 else q[c]) for q in pr], **kw) for c in range(nb)]
+        return torch.cat(rows)
 
     def generate(self, *args, use_cache=False, use_graph=False, **kw):
         """The reference loop; every step re-runs the decoder on the whole prefix (see the class docstring)."""

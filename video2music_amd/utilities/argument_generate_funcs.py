@@ -57,7 +57,7 @@ def parse_generate_args(argv=None):
     parser.add_argument("--midi", action="store_true",
                         help="also write <id>_chords.mid (voiced arpeggios, velocities from the regression head when --regression is set; "
                              "generate.py:446-607)")
-    parser.add_argument("--v2_streams", type=int, default=8, help="clips of a V2 run decoded concurrently (one stream + thread each)")
+    parser.add_argument("--v2_batch", type=int, default=32, help="clips of a V1 / V2 run decoded together in lockstep (one captured step graph)")
     parser.add_argument("--sampler", type=str, default="categorical", choices=["categorical", "multinomial", "argmax"],
                         help="beam=0 decision: categorical = on-device draw (default), multinomial = host torch.multinomial per step, argmax")
     parser.add_argument("--seed", type=int, default=1234)
