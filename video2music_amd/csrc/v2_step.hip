@@ -244,15 +244,39 @@ __global__ void rope_place_rows_kernel(const float* __restrict__ x, int ldx, con
     o[1] = y1 * scale;
 }
 
+// the three placements of a self-attention in one launch (blockIdx.z: 0 = query -> rotated, scaled, [B][E]; 1 = key -> rotated,
+// cache row t; 2 = value -> cache row t); qkv rows [B][3E]
+__global__ void place_qkv_rows_kernel(const float* __restrict__ qkv, const float* __restrict__ rope, float* __restrict__ q,
+                                      float* __restrict__ kc, float* __restrict__ vc, float qscale, int E, int hd, int cap,
+                                      const int* __restrict__ pos) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y, part = blockIdx.z;
+    if (2 * i >= E) return;
+    const int t = *pos;
+    const float* x = qkv + (size_t)b * 3 * E + (size_t)part * E;
+    const float x0 = x[2 * i], x1 = x[2 * i + 1];
+    float y0 = x0, y1 = x1;
+    if (rope && part < 2) {
+        const float c = rope[(size_t)t * E + 2 * i], sn = rope[(size_t)t * E + 2 * i + 1];
+        y0 = x0 * c - x1 * sn;
+        y1 = x1 * c + x0 * sn;
+    }
+    const int e = 2 * i, h = e / hd, cc = e - h * hd;
+    const float scale = part == 0 ? qscale : 1.f;
+    float* o = part == 0 ? q + (size_t)b * E + e : (part == 1 ? kc : vc) + (((size_t)b * (E / hd) + h) * cap + t) * hd + cc;
+    o[0] = y0 * scale;
+    o[1] = y1 * scale;
+}
+
 // row of expert e's output for clip b inside Y[n_exp][B][E]
 __global__ void dense_slot_kernel(const int* __restrict__ idx, int* __restrict__ slot_pos, int B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 2 * B) slot_pos[i] = idx[i] * B + (i >> 1);
 }
 
-int32_t lin_rows(const float* x, const float* wp, const float* b, const float* resid, float* y, int B, int N, int K, hipStream_t s) {
+int32_t lin_rows(const float* x, const float* wp, const float* b, const float* resid, float* y, int B, int N, int K, hipStream_t s,
+                 int ldx = 0) {
     DecodeGemmParams g{};
-    g.B = B; g.eps = 1e-5f; g.scale = 1.f; g.x = x; g.ldx = K; g.Wp = wp; g.bias = b; g.N = N; g.K = K;
+    g.B = B; g.eps = 1e-5f; g.scale = 1.f; g.x = x; g.ldx = ldx ? ldx : K; g.Wp = wp; g.bias = b; g.N = N; g.K = K;
     g.resid = resid; g.ldr = N; g.y = y; g.ldy = N;
     return amt_launch_decode_gemm(g, s);
 }
@@ -291,7 +315,8 @@ int32_t glu_rows(const float* x, const float* w1, const float* b1, const float* 
 }  // namespace
 
 extern "C" int64_t amt_v2_step_batch_ws_floats(int32_t E, int32_t dff, int32_t n_exp, int32_t B) {
-    return (int64_t)B * ((int64_t)(9 + n_exp) * E + 3 * dff + 8) + 64;
+    const int64_t ne = n_exp > 0 ? n_exp : 1;
+    return (int64_t)B * ((int64_t)(9 + n_exp) * E + 3 * ne * dff + 8) + 64;
 }
 
 extern "C" int32_t amt_v2_step_batch(const void* const* tab, int32_t n_layers, int32_t H, int32_t E, int32_t dff, int32_t n_exp,
@@ -309,8 +334,8 @@ extern "C" int32_t amt_v2_step_batch(const void* const* tab, int32_t n_layers, i
     float* x = ws; float* y = x + BE; float* qkv = y + BE; float* q = qkv + 3 * BE; float* o = q + BE; float* u = o + BE;
     float* ysh = u + BE;                                  // shared expert output [B][E]
     float* Yall = ysh + BE;                               // every expert's output [n_exp][B][E]
-    float* ffs = Yall + (size_t)n_exp * BE;               // 3*B*dff expert scratch
-    float* moe_w = ffs + (size_t)3 * B * dff;             // routing weights [B][2], indices [B][2], rows in Yall [B][2]
+    float* ffs = Yall + (size_t)n_exp * BE;               // 3 * B * max(n_exp, 1) * dff expert scratch
+    float* moe_w = ffs + (size_t)3 * B * (n_exp > 0 ? n_exp : 1) * dff;   // routing weights [B][2], indices [B][2], rows in Yall [B][2]
     int32_t* moe_idx = (int32_t*)(moe_w + 2 * B);
     int32_t* slot_pos = moe_idx + 2 * B;
     const int* pos = state_dev;
@@ -323,9 +348,8 @@ extern "C" int32_t amt_v2_step_batch(const void* const* tab, int32_t n_layers, i
         auto P = [&](int i) { return (const float*)L[i]; };
         float* kc = (float*)L[L_KC]; float* vc = (float*)L[L_VC];                 // [B][H][max_seq][hd]
         if ((rc = lin_rows(x, P(L_SAW), P(L_SAB), nullptr, qkv, B, 3 * E, E, s))) return rc;
-        if ((rc = place_rows(qkv, 3 * E, rope, q, qscale, B, E, hd, 0, pos, 0, s))) return rc;
-        if ((rc = place_rows(qkv + E, 3 * E, rope, kc, 1.f, B, E, hd, max_seq, pos, 1, s))) return rc;
-        if ((rc = place_rows(qkv + 2 * E, 3 * E, nullptr, vc, 1.f, B, E, hd, max_seq, pos, 1, s))) return rc;
+        hipLaunchKernelGGL(place_qkv_rows_kernel, dim3(cdiv(E / 2, 256), B, 3), dim3(256), 0, s, qkv, rope, q, kc, vc, qscale, E, hd, max_seq, pos);
+        AMT_LAUNCH_CHECK();
         if ((rc = attn_rows(q, kc, vc, o, B, H, hd, max_seq, 0, pos, s))) return rc;
         if ((rc = lin_rows(o, P(L_SAOW), P(L_SAOB), x, u, B, E, E, s))) return rc;
         if ((rc = norm_rows(u, nullptr, P(L_N1W), P(L_N1B), x, B, E, s))) return rc;
@@ -338,13 +362,18 @@ extern "C" int32_t amt_v2_step_batch(const void* const* tab, int32_t n_layers, i
             if ((rc = glu_rows(x, P(L_W1), P(L_B1), P(L_WG), P(L_BG), P(L_W2), P(L_B2), y, ffs, B, E, dff, s))) return rc;
         } else {
             if ((rc = amt_moe_route_fwd(x, P(L_GATEW), P(L_GATEB), moe_idx, moe_w, B, E, n_exp, s))) return rc;
-            const size_t pw1 = (size_t)dff * E, pw2 = (size_t)((E + 15) / 16 * 16) * dff;       // packed sizes per expert
-            for (int e = 0; e < n_exp; ++e) {
-                const float* w1 = P(L_W1) ? P(L_W1) + e * pw1 : nullptr;
-                const float* b1 = P(L_B1) ? P(L_B1) + (size_t)e * dff : nullptr;
-                if ((rc = glu_rows(x, w1, b1, P(L_WG) + e * pw1, P(L_BG) + (size_t)e * dff, P(L_W2) + e * pw2, P(L_B2) + (size_t)e * E,
-                                   Yall + e * BE, ffs, B, E, dff, s))) return rc;
-            }
+            // gate and up projections of ALL experts in one launch each: the experts' packed weights lie one after the other,
+            // which is the packed form of the stacked (n_exp*dff, E) matrix (tiles of 16 output rows, dff % 16 == 0)
+            const int Nall = n_exp * dff;
+            float* Gall = ffs; float* Uall = Gall + (size_t)B * Nall; float* Hall = Uall + (size_t)B * Nall;
+            if ((rc = lin_rows(x, P(L_WG), P(L_BG), nullptr, Gall, B, Nall, E, s))) return rc;
+            if (P(L_W1) && (rc = lin_rows(x, P(L_W1), P(L_B1), nullptr, Uall, B, Nall, E, s))) return rc;
+            hipLaunchKernelGGL(glu_mul_kernel, dim3(cdiv(B * Nall, 1024)), dim3(256), 0, s, P(L_W1) ? Uall : nullptr, Gall, Hall, B * Nall);
+            AMT_LAUNCH_CHECK();
+            const size_t pw2 = (size_t)E * dff;                                                  // packed linear2 per expert
+            for (int e = 0; e < n_exp; ++e)
+                if ((rc = lin_rows(Hall + (size_t)e * dff, P(L_W2) + e * pw2, P(L_B2) + (size_t)e * E, nullptr, Yall + e * BE, B, E, dff, s, Nall)))
+                    return rc;
             hipLaunchKernelGGL(dense_slot_kernel, dim3(cdiv(2 * B, 256)), dim3(256), 0, s, moe_idx, slot_pos, B);
             AMT_LAUNCH_CHECK();
             const float* shared = nullptr;
