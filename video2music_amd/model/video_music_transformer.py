@@ -555,11 +555,18 @@ class VideoMusicTransformer_V2(nn.Module):
         q = ops.linear(xq, W[:E], b[:E])
         k = ops.linear(xkv, W[E:2 * E], b[E:2 * E])
         v = ops.linear(xkv, W[2 * E:], b[2 * E:])
-        if self._rope_cache is not None:
+        clips = getattr(self, "_clip_rows", False)
+        if self._rope_cache is not None and clips:
+            # independent clips, rows clip-major (B*L, E): each clip gets what the raw view does for a batch of one, i.e.
+            # pair i of the E-wide vector at position l rotated by cache[l][i] -- one launch for all clips
+            q = ops.rope(q.view(B, Lq, 1, E), self._rope_cache).view(Lq * B, E)
+            k = ops.rope(k.view(B, Lk, 1, E), self._rope_cache).view(Lk * B, E)
+        elif self._rope_cache is not None:
             q = ops.rope(q.view(H, Lq, B, hd), self._rope_cache).view(Lq * B, E)       # raw (H, L, B, hd) view (:1041-1053)
             k = ops.rope(k.view(H, Lk, B, hd), self._rope_cache).view(Lk * B, E)
         o = torch.empty(Lq * B, E, device=xq.device, dtype=torch.float32)
-        st = (E, hd, B * E) * 4                                                     # (L, B, E) buffers: b, h, l strides
+        # b, h, l strides of q, k, v, o: (L, B, E) seq-first buffers, or (B, L, E) clip-major ones
+        st = ((Lq * E, hd, E) + (Lk * E, hd, E) * 2 + (Lq * E, hd, E)) if clips else (E, hd, B * E) * 4
         ops.attention(q, k, v, st, B, H, Lq, Lk, hd, causal, 1.0 / math.sqrt(hd), o)
         return ops.linear(o, a.out_proj.weight.detach(), a.out_proj.bias.detach(), resid=resid)
 
@@ -576,8 +583,10 @@ class VideoMusicTransformer_V2(nn.Module):
             return ops.rmsnorm(t, n.weight.detach(), resid=resid, eps=n.eps)
         return ops.layernorm(t, n.weight.detach(), n.bias.detach(), resid=resid, eps=n.eps)
 
-    def _encode_memory(self, feature_semantic_list, feature_scene_offset, feature_motion, feature_emotion):
-        """Video stream + encoder stack (:455-487 and the encoder half of :505): (S*B, d) seq-first rows, B, S."""
+    def _encode_memory(self, feature_semantic_list, feature_scene_offset, feature_motion, feature_emotion, clips=False):
+        """Video stream + encoder stack (:455-487 and the encoder half of :505): (S*B, d) seq-first rows, B, S.
+        clips=True: the B clips are encoded as B independent batches of one (what B calls with one clip each compute; for
+        B > 1 the reference's raw RoPE view ties the clips of a batch together) in one pass; rows come back clip-major."""
         from .. import ops
         self._derived()
         dev = self.Wout.weight.device
@@ -593,9 +602,13 @@ class VideoMusicTransformer_V2(nn.Module):
             pos_rows = self.positional_embedding_video.weight.detach()[:S].unsqueeze(0).expand(B, S, d).contiguous().view(B * S, d)
         vf = ops.linear(ops.concat_features(sem, scene, motion, emotion, self._Fpad), self._Wvis_pad, self.Linear_vis.bias.detach(),
                         resid=pos_rows)
-        src = vf.view(B, S, d).permute(1, 0, 2).contiguous().view(S * B, d)
-        for lyr in self.transformer.encoder.layers:
-            src = self._enc_layer(src, lyr, S, B)
+        src = vf if clips else vf.view(B, S, d).permute(1, 0, 2).contiguous().view(S * B, d)
+        self._clip_rows = bool(clips)
+        try:
+            for lyr in self.transformer.encoder.layers:
+                src = self._enc_layer(src, lyr, S, B)
+        finally:
+            self._clip_rows = False
         return self._ln(src, self.transformer.encoder.norm), B, S
 
     def _enc_layer(self, src, lyr, S, B):
@@ -837,8 +850,9 @@ class VideoMusicTransformer_V2(nn.Module):
         generates one clip per call).  Features (B, S, .), key (B,) / (B, 1); primers (P,) shared or (B, P).
 
         The clips advance in lockstep through one captured step graph (`amt_v2_step_batch`): each projection reads its
-        weights once per step for all clips.  The video encoder runs per clip (for B > 1 the reference's raw RoPE view
-        would tie the clips of a batch together); the per-step decision runs on the host as in `generate`."""
+        weights once per step for all clips.  The video encoder runs once over all clips as independent batches of one (for B > 1
+        the reference's raw RoPE view would tie the clips of a batch together); the per-step decision runs on the host as in
+        `generate`."""
         from ..utilities.constants import chord_to_root_attr
         assert (not self.training), "Cannot generate while in training mode"
         if beam not in (0, 1):
@@ -859,11 +873,8 @@ class VideoMusicTransformer_V2(nn.Module):
             gen_root[:, :P], gen_attr[:, :] = gen[:, :P], 0
         key = feature_key.to(dtype=torch.float32).reshape(-1)
         key = (key.expand(nb) if key.numel() == 1 else key).contiguous()
-        mems, S = [], None
-        for c in range(nb):
-            sl = slice(c, c + 1)
-            m, _, S = self._encode_memory(feature_semantic_list[sl], feature_scene_offset[sl], feature_motion[sl], feature_emotion[sl])
-            mems.append(m)
+        rows, _, S = self._encode_memory(feature_semantic_list, feature_scene_offset, feature_motion, feature_emotion, clips=True)
+        mems = [rows[c * S:(c + 1) * S] for c in range(nb)]
         st = self._cache_init(mems, S)
         if nb == 1 or not st["native"]:            # one clip, or layers of unequal width: the single-clip loop
             rows = [self.generate(feature_semantic_list[c:c + 1], key[c], feature_scene_offset[c:c + 1], feature_motion[c:c + 1],
@@ -886,15 +897,25 @@ class VideoMusicTransformer_V2(nn.Module):
             graph = torch.cuda.CUDAGraph()
             with _CAPTURE_LOCK, torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 self._step_batch(st, keys, state)
+        # the host decision works on (B, 159) tensors: with torch's intra-op pool awake each such op costs milliseconds
+        # (6 ms for the softmax alone, found with cProfile), so the loop runs with one intra-op thread
+        n_threads = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            return self._lockstep_loop(st, keys, state, feed, graph, gen, gen_root, gen_attr, ra_table, nb, T, P, beam, max_conseq_N,
+                                       max_conseq_chord, temperature, sampler).to(dev)
+        finally:
+            torch.set_num_threads(n_threads)
+
+    def _lockstep_loop(self, st, keys, state, feed, graph, gen, gen_root, gen_attr, ra_table, nb, T, P, beam, max_conseq_N,
+                       max_conseq_chord, temperature, sampler):
         for cur in range(1, T):
             if cur - 1 > 0:                                             # logits of input position cur-1
                 feed(cur - 1)
                 graph.replay() if graph is not None else self._step_batch(st, keys, state)
             if cur < P:
                 continue
-            # row by row, the arithmetic of `generate` (and a (B, 159) CPU softmax would wake torch's whole thread pool)
-            lg = st["logits"].cpu()
-            probs = torch.stack([torch.softmax(row / temperature, dim=-1)[:CHORD_END] for row in lg])
+            probs = torch.softmax(st["logits"].cpu() / temperature, dim=-1)[:, :CHORD_END]     # per row the arithmetic of `generate`
             if beam == 1:
                 tok = probs.argmax(-1)                                  # topk(., 1) per clip (:547-560); no root/attr feedback
                 gen[:, cur] = tok
@@ -914,7 +935,7 @@ class VideoMusicTransformer_V2(nn.Module):
                 tok = torch.distributions.categorical.Categorical(probs=probs).sample()
             gen[:, cur] = tok
             gen_root[:, cur], gen_attr[:, cur] = (tok, 0) if self.chord_embed else (ra_table[tok, 0], ra_table[tok, 1])
-        return gen.to(dev)
+        return gen
 
     def generate(self, feature_semantic_list=[], feature_key=None, feature_scene_offset=None, feature_motion=None,
                  feature_emotion=None, primer=None, primer_root=None, primer_attr=None, target_seq_length=300, beam=0,
