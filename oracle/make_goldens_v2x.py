@@ -1,6 +1,6 @@
 """Golden fixtures of the other VideoMusicTransformer_V2 variants, from the REFERENCE class
 itself on CPU: version '2.0' (learned positional tables, no RoPE), '2.1' (top-k scheduler: training only), and '2.2' with
-chord_embed=True (chord ids through a frozen table).
+chord_embed=True (chord ids through a frozen table) or scene_embed=True (scene offsets through an embedding).
 
 TEST INFRASTRUCTURE; runs only in the build container:  PYTHONDONTWRITEBYTECODE=1 python oracle/make_goldens_v2x.py
 
@@ -30,9 +30,12 @@ def main():
     feats = synthetic.synthetic_features(3, seed=1234)
     key = np.array([[0.0], [1.0], [0.0]], dtype=np.float32)
     out = {}
-    for tag, version, chord_embed in (("v20", "2.0", False), ("v21", "2.1", False), ("v22ce", "2.2", True)):
+    for tag, version, chord_embed, scene_embed in (("v20", "2.0", False, False), ("v21", "2.1", False, False), ("v22ce", "2.2", True, False),
+                                                   ("v22se", "2.2", False, True)):
+        # scene_embed: the scene offset indexes an embedding instead of being a feature column (:463-465,481-484), so the
+        # caller passes a total_vf_dim without that column
         cfg = dict(version_name=version, n_layers=6, num_heads=4, d_model=128, dim_feedforward=256, max_sequence_chord=300,
-                   total_vf_dim=synthetic.total_vf_dim(1))
+                   total_vf_dim=synthetic.total_vf_dim(1) - int(scene_embed), scene_embed=scene_embed)
         m = ref.vmt.VideoMusicTransformer_V2(**cfg).eval()
         MG.load_synthetic(m, seed=0)
         if chord_embed:

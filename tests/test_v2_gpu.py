@@ -117,10 +117,12 @@ def _variant(version, chord_embed=False, **extra):
     return m.cuda()
 
 
-@pytest.mark.parametrize("tag,version,ce", [("v20", "2.0", False), ("v21", "2.1", False), ("v22ce", "2.2", True)])
+@pytest.mark.parametrize("tag,version,ce", [("v20", "2.0", False), ("v21", "2.1", False), ("v22ce", "2.2", True), ("v22se", "2.2", False)])
 def test_v2_variants_vs_reference_golden(golden, tag, version, ce):
     g = golden("g_v2_variants.npz")
-    m = _variant(version, ce, rms_norm=(version == "2.1"))          # rms_norm has no effect in V2, as in the reference
+    extra = dict(scene_embed=True, total_vf_dim=CFG_V2["total_vf_dim"] - 1) if tag == "v22se" else {}
+    m = _variant(version, ce, rms_norm=(version == "2.1"), **extra)          # rms_norm has no effect in V2, as in the reference
+    assert ("scene_embedding.weight" in m.state_dict()) == (tag == "v22se")
     assert ("positional_embedding.weight" in m.state_dict()) == (version == "2.0")
     assert ("chord_embedding_model.weight" in m.state_dict()) == ce
     key = np.array([[0.0], [1.0], [0.0]], dtype=np.float32)

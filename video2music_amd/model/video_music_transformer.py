@@ -457,8 +457,8 @@ class VideoMusicTransformer_V2(nn.Module):
         self._use_rope = (not self._learned_pos) and version_name in ("2.1", "2.2", "2.3")
         if version_name in "2.3":
             raise NotImplementedError("version '2.3' swaps the experts for efficient_kan.KANLinear, a package the reference does not vendor")
-        if scene_embed or dropTokenRate != 0.0:
-            raise NotImplementedError("scene_embed / dropTokenRate (a random mask applied even in eval, :484-488) are outside this path")
+        if dropTokenRate != 0.0:
+            raise NotImplementedError("dropTokenRate (a random mask applied even in eval, :484-488) is outside this path")
         # rms_norm is accepted and has no effect, as in the reference (its RMSNorm branch is commented out, :364-371);
         # '2.1' differs from '2.2' by a top-k scheduler that only acts in training (moe.py:232-236)
         if n_layers < 3:
@@ -468,6 +468,8 @@ class VideoMusicTransformer_V2(nn.Module):
         self.scene_embed, self.chord_embed, self.dropTokenRate, self.version_name = scene_embed, chord_embed, dropTokenRate, version_name
         self.total_vf_dim = total_vf_dim
         self.n_experts, self.n_experts_per_token = 6, 2
+        if scene_embed:                          # vf = Linear_vis(features without the scene column) + scene_embedding(offset) (:336-337,481-484)
+            self.scene_embedding = nn.Embedding(SCENE_OFFSET_MAX, d_model)
         if chord_embed:
             # the reference fills this frozen table from a gensim Word2Vec file (:340-344); here it arrives with the
             # state_dict (key chord_embedding_model.weight, any number of rows >= the ids fed; vector size = d_model)
@@ -537,14 +539,28 @@ class VideoMusicTransformer_V2(nn.Module):
             else:
                 self._PR = ops.linear(self.embedding_root.weight.detach().contiguous(), Wc_main)
                 self._PA = ops.linear(self.embedding_attr.weight.detach().contiguous(), Wc_main)
-            self._Fpad = (F + 31) // 32 * 32
-            Wv = torch.zeros(d, self._Fpad, device=dev)
-            Wv[:, :F] = self.Linear_vis.weight.detach()
-            self._Wvis_pad = Wv
+            self._wvis_cache = {}
             # positional rows added to the chord embedding: the learned table of version '2.0' (:497-503) or none
             self._pe_chord = (self.positional_embedding.weight.detach().contiguous() if self._learned_pos
                               else torch.zeros(self._max_dec, d, device=dev))
             self._derived_sig = sig
+
+    def _wvis(self, sem_dim):
+        """Linear_vis.weight laid out for the rows of `concat_features` ([semantic | scene | motion | emotion], zero-padded
+        to a multiple of 32 columns).  With scene_embed the reference leaves the scene column out of the features (:463-465):
+        the weight then gets a zero column at that place, so the same rows serve."""
+        if sem_dim not in self._wvis_cache:
+            W = self.Linear_vis.weight.detach()
+            d, F = W.shape
+            cols = F + 1 if self.scene_embed else F
+            Fpad = (cols + 31) // 32 * 32
+            Wv = torch.zeros(d, Fpad, device=W.device)
+            if self.scene_embed:
+                Wv[:, :sem_dim], Wv[:, sem_dim + 1:cols] = W[:, :sem_dim], W[:, sem_dim:]
+            else:
+                Wv[:, :F] = W
+            self._wvis_cache[sem_dim] = (Wv, Fpad)
+        return self._wvis_cache[sem_dim]
 
     def _attention(self, xq, xkv, a, Lq, Lk, B, causal, resid):
         """xq (Lq*B, E), xkv (Lk*B, E) seq-first rows; returns out-proj(attn) + resid."""
@@ -600,8 +616,11 @@ class VideoMusicTransformer_V2(nn.Module):
         pos_rows = None
         if self._learned_pos:                                   # vf += positional_embedding_video(arange(S)) (:499-501)
             pos_rows = self.positional_embedding_video.weight.detach()[:S].unsqueeze(0).expand(B, S, d).contiguous().view(B * S, d)
-        vf = ops.linear(ops.concat_features(sem, scene, motion, emotion, self._Fpad), self._Wvis_pad, self.Linear_vis.bias.detach(),
-                        resid=pos_rows)
+        Wv, Fpad = self._wvis(sem.shape[2])
+        if self.scene_embed:                                    # + scene_embedding(feature_scene_offset.int()) (:481-484)
+            srows = self.scene_embedding.weight.detach()[scene.to(torch.int32).long()].reshape(B * S, d).contiguous()
+            pos_rows = srows if pos_rows is None else ops.add(pos_rows, srows)
+        vf = ops.linear(ops.concat_features(sem, scene, motion, emotion, Fpad), Wv, self.Linear_vis.bias.detach(), resid=pos_rows)
         src = vf if clips else vf.view(B, S, d).permute(1, 0, 2).contiguous().view(S * B, d)
         self._clip_rows = bool(clips)
         try:
@@ -1032,8 +1051,8 @@ class VideoMusicTransformer_V1(VideoMusicTransformer_V2):
                  max_sequence_midi=2048, max_sequence_video=300, max_sequence_chord=300, total_vf_dim=0, rms_norm=False,
                  scene_embed=False, chord_embed=False, dropTokenRate=0.0):
         nn.Module.__init__(self)
-        if scene_embed or dropTokenRate != 0.0:
-            raise NotImplementedError("scene_embed / dropTokenRate (a random mask applied even in eval, :191-196) are outside this path")
+        if dropTokenRate != 0.0:
+            raise NotImplementedError("dropTokenRate (a random mask applied even in eval, :191-196) is outside this path")
         from .custom_transformer import RMSNorm
         from .moe import GLUExpert, MoELayer, SharedMoELayer, SiLUExpert
         shallow = version_name in ("1.3.3", "1.3.4")
@@ -1046,6 +1065,8 @@ class VideoMusicTransformer_V1(VideoMusicTransformer_V2):
         self.n_experts, self.n_experts_per_token = 6, 2
         self._learned_pos = True
         self._use_rope = version_name in "1.2.3"                     # substring test, as written at :86
+        if scene_embed:                          # vf = Linear_vis(features without the scene column) + scene_embedding(offset) (:336-337,481-484)
+            self.scene_embedding = nn.Embedding(SCENE_OFFSET_MAX, d_model)
         if chord_embed:
             self.chord_embedding_model = nn.Embedding(CHORD_SIZE, d_model)
             self.chord_embedding_model.weight.requires_grad_(False)
@@ -1140,8 +1161,8 @@ class VideoMusicTransformer_V3(VideoMusicTransformer_V2):
         nn.Module.__init__(self)
         if version_name not in ("3.0", "3.1", "3.2"):
             raise ValueError("the reference builds an encoder for '3.0', '3.1' and '3.2' only (:672-690)")
-        if scene_embed or dropTokenRate != 0.0:
-            raise NotImplementedError("scene_embed / dropTokenRate (a random mask applied even in eval) are outside this path")
+        if dropTokenRate != 0.0:
+            raise NotImplementedError("dropTokenRate (a random mask applied even in eval) is outside this path")
         if n_layers < 3:
             raise ValueError("the reference builds 3 shallow + (n_layers-3) deep layers")
         from .custom_transformer import RMSNorm
@@ -1154,6 +1175,8 @@ class VideoMusicTransformer_V3(VideoMusicTransformer_V2):
         self.n_experts, self.n_experts_per_token = 6, 2
         self._learned_pos, self._use_rope = False, True
         self.pre_norm = version_name == "3.2"
+        if scene_embed:                          # vf = Linear_vis(features without the scene column) + scene_embedding(offset) (:336-337,481-484)
+            self.scene_embedding = nn.Embedding(SCENE_OFFSET_MAX, d_model)
         if chord_embed:
             self.chord_embedding_model = nn.Embedding(CHORD_SIZE, d_model)
             self.chord_embedding_model.weight.requires_grad_(False)
