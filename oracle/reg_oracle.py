@@ -81,6 +81,11 @@ def bimamba_layer(x, sd, p, version=1):
     xb = mamba_block(torch.flip(x, dims=[1]), sd, p + "mamba_backward.", version)
     xb = layer_norm(torch.flip(xb, dims=[1]) + x, sd[p + "norm2.weight"], sd[p + "norm2.bias"])
     s = xf + xb
+    if p + "ffn.gate.weight" in sd:             # a mixture layer in the FFN's place ('moe_bimamba+' / 'sharedmoe_bimamba+')
+        from oracle.amt_oracle import moe_forward
+        sub = {k[len(p) + 4:]: v for k, v in sd.items() if k.startswith(p + "ffn.")}
+        f = moe_forward(s, sub, sub["gate.weight"].shape[0], k=2, shared="shared_expert.gate.weight" in sub)
+        return layer_norm(f + s, sd[p + "norm3.weight"], sd[p + "norm3.bias"])
     f = linear(torch.relu(linear(s, sd[p + "ffn.0.weight"], sd[p + "ffn.0.bias"])), sd[p + "ffn.3.weight"], sd[p + "ffn.3.bias"])
     return layer_norm(f + s, sd[p + "norm3.weight"], sd[p + "norm3.bias"])
 
@@ -116,6 +121,7 @@ def forward(sd, sem, emotion, collect=None, reg_model="bimamba+"):
     Scene offset and motion are accepted by the reference's signature but not used (:205-213 are commented out).
     reg_model: 'bimamba+' / 'bimamba' (BiMambaEncoder) or 'mamba+' / 'mamba' (Mamba stack); '+' = use_version 1."""
     version = 1 if reg_model.endswith("+") else 0
+    reg_model = reg_model.replace("sharedmoe_", "").replace("moe_", "")       # same layers; the mixture shows in the keys
     sd = {k: v.float() for k, v in sd.items()}
     vf = torch.cat([sem.float(), emotion.float()], dim=-1)
     x = linear(vf, sd["in_proj.0.weight"], sd["in_proj.0.bias"])

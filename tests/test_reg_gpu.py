@@ -96,7 +96,7 @@ def test_rejects_unbuilt_variants():
         m(torch.zeros(1, 4, 20).cuda(), None, None, torch.zeros(1, 4, 6).cuda())
 
 
-@pytest.mark.parametrize("rm", ["bimamba", "mamba", "mamba+"])
+@pytest.mark.parametrize("rm", ["bimamba", "mamba", "mamba+", "moe_bimamba+", "sharedmoe_bimamba+"])
 def test_other_mamba_regmodels_vs_reference_golden(golden, rm):
     g = golden("g_reg.npz")
     m, _ = build(dict(n_layers=2, d_model=32, d_hidden=64, total_vf_dim=30, regModel=rm), seed=5)

@@ -91,24 +91,43 @@ def expert_parts(e):
     return {"linear1": e.linear1, "gate": e.gate, "linear2": e.linear2}
 
 
-def expert_tensors(e):
-    """(w1, b1, wg, bg, w2, b2) contiguous, None where the expert has no such tensor."""
-    q = expert_parts(e)
-    out = []
-    for name in ("linear1", "gate", "linear2"):
-        out += [None, None] if q[name] is None else [q[name].weight.detach().contiguous(), q[name].bias.detach().contiguous()]
+def expert_dff(e):
+    """Hidden width as the kernels see it: a multiple of 32 (the GEMM's K step).  An odd width -- the regression head's
+    GLUExpert(d, 2d + 1), video_regression.py:149,166,174 -- is zero-padded: the extra hidden units compute
+    (0 + 0) * silu(0) = 0 and meet zero columns of linear2, so the result is unchanged."""
+    return (expert_parts(e)["gate"].out_features + 31) // 32 * 32
+
+
+def _slot_tensor(lin, name, field, width):
+    """weight / bias of one slot, hidden dimension zero-padded to `width`."""
+    t = getattr(lin, field).detach()
+    have = lin.out_features if name != "linear2" else lin.in_features
+    if have == width or (name == "linear2" and field == "bias"):
+        return t.contiguous()
+    if name == "linear2":                                   # (d, dff): pad columns
+        out = torch.zeros(t.shape[0], width, dtype=t.dtype, device=t.device)
+        out[:, :have] = t
+    else:                                                   # (dff, d) or (dff,): pad rows
+        out = torch.zeros((width,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        out[:have] = t
     return out
 
 
-def expert_dff(e):
-    return expert_parts(e)["gate"].out_features
+def expert_tensors(e):
+    """(w1, b1, wg, bg, w2, b2) contiguous, None where the expert has no such tensor."""
+    q, width = expert_parts(e), expert_dff(e)
+    out = []
+    for name in ("linear1", "gate", "linear2"):
+        out += [None, None] if q[name] is None else [_slot_tensor(q[name], name, "weight", width), _slot_tensor(q[name], name, "bias", width)]
+    return out
 
 
 def _stack(mods, attr, field):
     lins = [expert_parts(m)[attr] for m in mods]
     if lins[0] is None:
         return None
-    return torch.stack([getattr(l, field).detach() for l in lins]).contiguous()
+    width = expert_dff(mods[0])
+    return torch.stack([_slot_tensor(l, attr, field, width) for l in lins]).contiguous()
 
 
 class _MoEBase(nn.Module):

@@ -42,14 +42,18 @@ class _MambaBlockParams(nn.Module):
 
 
 class _BiMambaLayerParams(nn.Module):
-    """BiMambaEncoderLayer_V1 (bimamba.py:102-133), plain FFN."""
+    """BiMambaEncoderLayer_V1 (bimamba.py:102-133): plain FFN, or a copy of `moe` (a mixture layer) in its place."""
 
-    def __init__(self, d_model, d_hidden):
+    def __init__(self, d_model, d_hidden, moe=None):
         super().__init__()
         self.mamba_forward = _MambaBlockParams(d_model)
         self.mamba_backward = _MambaBlockParams(d_model)
         self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d_model), nn.LayerNorm(d_model), nn.LayerNorm(d_model)
-        self.ffn = nn.Sequential(nn.Linear(d_model, d_hidden), nn.ReLU(), nn.Dropout(0.0), nn.Linear(d_hidden, d_model))
+        if moe is None:
+            self.ffn = nn.Sequential(nn.Linear(d_model, d_hidden), nn.ReLU(), nn.Dropout(0.0), nn.Linear(d_hidden, d_model))
+        else:
+            import copy
+            self.ffn = copy.deepcopy(moe)
 
 
 class _RMSWeight(nn.Module):
@@ -89,28 +93,36 @@ class _BiMambaLayerV0Params(nn.Module):
 
 
 class _BiMambaEncoderParams(nn.Module):
-    def __init__(self, d_model, d_hidden, n_layers, version=1):
+    def __init__(self, d_model, d_hidden, n_layers, version=1, moe=None):
         super().__init__()
-        layer = _BiMambaLayerParams if version == 1 else _BiMambaLayerV0Params          # bimamba.py:16-19
-        self.layers = nn.ModuleList([layer(d_model, d_hidden) for _ in range(n_layers)])
+        if version == 1:                                                                # bimamba.py:16-19
+            self.layers = nn.ModuleList([_BiMambaLayerParams(d_model, d_hidden, moe) for _ in range(n_layers)])
+        else:
+            self.layers = nn.ModuleList([_BiMambaLayerV0Params(d_model, d_hidden) for _ in range(n_layers)])
 
 
 class VideoRegression(nn.Module):
     def __init__(self, n_layers=2, d_model=64, d_hidden=1024, dropout=0.1, use_KAN=False, max_sequence_video=300,
                  total_vf_dim=0, regModel="bilstm", scene_embed=False, chord_embed=False):
         super().__init__()
-        if regModel not in ("bimamba+", "bimamba", "mamba", "mamba+"):
-            raise NotImplementedError("built: regModel 'bimamba+' (the callers' default), 'bimamba', 'mamba', 'mamba+'; the LSTM / GRU / "
-                                      "CNN-GRU / minGRU and the MoE-Mamba variants of video_regression.py:124-178 are not")
+        if regModel not in ("bimamba+", "bimamba", "mamba", "mamba+", "moe_bimamba+", "sharedmoe_bimamba+"):
+            raise NotImplementedError("built: regModel 'bimamba+' (the callers' default), 'bimamba', 'mamba', 'mamba+', 'moe_bimamba+', "
+                                      "'sharedmoe_bimamba+'; the LSTM / GRU / CNN-GRU / minGRU heads and 'moemamba' (d_state = d_hidden) "
+                                      "of video_regression.py:124-178 are not")
         self._version = 1 if regModel.endswith("+") else 0           # MambaConfig.use_version: 1 = the Mamba+ gate
-        self._bidirectional = regModel.startswith("bi")
+        self._bidirectional = "bimamba" in regModel
+        moe = None
+        if regModel in ("moe_bimamba+", "sharedmoe_bimamba+"):     # GLUExpert(d, 2d + 1), 6 experts, top-2 (:165-178)
+            from .moe import GLUExpert, MoELayer, SharedMoELayer
+            cls = MoELayer if regModel == "moe_bimamba+" else SharedMoELayer
+            moe = cls(GLUExpert(d_model, d_model * 2 + 1), d_model, n_experts=6, n_experts_per_token=2, dropout=dropout)
         if use_KAN or scene_embed or chord_embed:
             raise NotImplementedError("use_KAN / scene_embed / chord_embed are outside this path")
         if d_model % 32 != 0 or d_hidden % 32 != 0:
             raise ValueError("d_model and d_hidden must be multiples of 32 (GEMM K step)")
         self.n_layers, self.d_model, self.d_hidden = n_layers, d_model, d_hidden
         self.max_seq_video, self.total_vf_dim, self.regModel = max_sequence_video, total_vf_dim, regModel
-        self.model = (_BiMambaEncoderParams(d_model, d_hidden, n_layers, self._version) if self._bidirectional
+        self.model = (_BiMambaEncoderParams(d_model, d_hidden, n_layers, self._version, moe) if self._bidirectional
                       else _MambaStackParams(d_model, n_layers))
         self.in_proj = nn.Sequential(nn.Linear(total_vf_dim, d_model), nn.Dropout(dropout))
         self.regressor = nn.Linear(d_model, 2)
@@ -189,9 +201,12 @@ class VideoRegression(nn.Module):
                                     lyr.norm1.weight.detach(), lyr.norm1.bias.detach(), eps=lyr.norm1.eps)
             s = ops.layernorm_post(self._mamba(x, lyr.mamba_backward, self._Wdt[2 * i + 1], self._Wx[2 * i + 1], B, S, x, True),
                                    lyr.norm2.weight.detach(), lyr.norm2.bias.detach(), post=xf, eps=lyr.norm2.eps)      # x_f + x_b
-            h = ops.linear_ex(s, lyr.ffn[0].weight.detach(), lyr.ffn[0].bias.detach(), act=1)
-            f = ops.linear_ex(h, lyr.ffn[3].weight.detach(), lyr.ffn[3].bias.detach(), resid=s)
-            x = ops.layernorm_post(f, lyr.norm3.weight.detach(), lyr.norm3.bias.detach(), eps=lyr.norm3.eps)
+            if isinstance(lyr.ffn, nn.Sequential):
+                h = ops.linear_ex(s, lyr.ffn[0].weight.detach(), lyr.ffn[0].bias.detach(), act=1)
+                f, r = ops.linear_ex(h, lyr.ffn[3].weight.detach(), lyr.ffn[3].bias.detach(), resid=s), None
+            else:                                       # the mixture layer in the FFN's place; the residual enters the norm
+                f, r = lyr.ffn(s.view(B, S, self.d_model)).reshape(B * S, self.d_model), s
+            x = ops.layernorm_post(f, lyr.norm3.weight.detach(), lyr.norm3.bias.detach(), resid=r, eps=lyr.norm3.eps)
         return x.view(B, S, self.d_model)
 
     def forward(self, feature_semantic_list, feature_scene_offset, feature_motion, feature_emotion):
