@@ -249,6 +249,14 @@ int64_t amt_v2_step_ws_floats(int32_t E, int32_t dff, int32_t n_exp);
 int32_t amt_v2_step(const void* const* tab, int32_t n_layers, int32_t H, int32_t E, int32_t dff, int32_t n_exp,
                     int32_t S, int32_t max_seq, int32_t t, int32_t root, int32_t attr, float key, const int32_t* state_dev,
                     float* logits_out, float* ws, void* stream);
+/* ---- regression head, recurrent variants (video_regression.py:124-135: torch.nn.LSTM / nn.GRU, batch_first) -------------
+ * The recurrence of one layer and direction over projected inputs xproj (B, L, ldxp) whose columns [0, gates*d) hold
+ * W_ih x + b_ih (gate order of torch: LSTM i,f,g,o; GRU r,z,n): gates = 4 LSTM, 3 GRU; w_hh (gates*d, d), b_hh (gates*d);
+ * y (B, L, ldy) receives h_t in columns [0, d) of the pointer given (pass y + d for the reverse direction of a
+ * bidirectional layer); reverse = 1 walks t = L-1 .. 0 and writes h at t.  d a multiple of 8, at most 128. */
+int32_t amt_rnn_seq_fwd(const float* xproj, int32_t ldxp, const float* w_hh, const float* b_hh, float* y, int32_t ldy,
+                        int32_t B, int32_t L, int32_t d, int32_t gates, int32_t reverse, void* stream);
+
 /* The same step for B independent clips in lockstep (all at one position): projections are one launch over B rows (weights
  * read once per step, not once per clip), the caches carry a leading clip dimension (self K/V: B, H, max_seq, hd; cross K/V:
  * B, H, S, hd), a mixture layer evaluates all experts on all rows and combines each row's routed pair in expert-index

@@ -116,6 +116,38 @@ def residual_block(x, sd, p, version):
     return mamba_block(h, sd, p + "mixer.", version) + x
 
 
+def rnn_stack(x, sd, kind, bidirectional):
+    """torch.nn.LSTM / nn.GRU, batch_first, eval (the reference builds them at video_regression.py:124-135; the cell
+    equations are torch's documented ones).  x (B, L, d); keys model.weight_ih_l{k}[_reverse] etc.; gate order i,f,g,o / r,z,n."""
+    n = 0
+    while f"model.weight_ih_l{n}" in sd:
+        n += 1
+    for l in range(n):
+        outs = []
+        for rev in ([False, True] if bidirectional else [False]):
+            sfx = f"_l{l}" + ("_reverse" if rev else "")
+            Wi, Wh, bi, bh = (sd[f"model.{k}{sfx}"] for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+            d = Wh.shape[1]
+            B, L, _ = x.shape
+            h, c = torch.zeros(B, d, dtype=x.dtype), torch.zeros(B, d, dtype=x.dtype)
+            ys = [None] * L
+            for t in (range(L - 1, -1, -1) if rev else range(L)):
+                gx, gh = x[:, t] @ Wi.t() + bi, h @ Wh.t() + bh
+                if kind == "lstm":
+                    i, f, g, o = (gx + gh).chunk(4, dim=-1)
+                    c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+                    h = torch.sigmoid(o) * torch.tanh(c)
+                else:
+                    xr, xz, xn = gx.chunk(3, dim=-1)
+                    hr, hz, hn = gh.chunk(3, dim=-1)
+                    r, z = torch.sigmoid(xr + hr), torch.sigmoid(xz + hz)
+                    h = (1 - z) * torch.tanh(xn + r * hn) + z * h
+                ys[t] = h
+            outs.append(torch.stack(ys, 1))
+        x = torch.cat(outs, dim=-1)
+    return x
+
+
 def forward(sd, sem, emotion, collect=None, reg_model="bimamba+"):
     """VideoRegression.forward (video_regression.py:199-245): returns (loudness_notedensity (B,S,2), instrument (B,S,40)).
     Scene offset and motion are accepted by the reference's signature but not used (:205-213 are commented out).
@@ -127,7 +159,9 @@ def forward(sd, sem, emotion, collect=None, reg_model="bimamba+"):
     x = linear(vf, sd["in_proj.0.weight"], sd["in_proj.0.bias"])
     if collect is not None:
         collect["in_proj"] = x
-    for l in range(n_layers_of(sd)):
+    if reg_model in ("lstm", "bilstm", "gru", "bigru"):
+        x = rnn_stack(x, sd, "lstm" if "lstm" in reg_model else "gru", reg_model.startswith("bi"))
+    for l in range(0 if reg_model in ("lstm", "bilstm", "gru", "bigru") else n_layers_of(sd)):
         p = f"model.layers.{l}."
         if reg_model.startswith("bi"):
             x = bimamba_layer(x, sd, p, 1) if version == 1 else bimamba_layer_v0(x, sd, p)

@@ -90,13 +90,15 @@ def test_deployed_size_vs_oracle_and_postprocessing():
 
 def test_rejects_unbuilt_variants():
     with pytest.raises(NotImplementedError):
-        VideoRegression(total_vf_dim=774, regModel="bilstm")
+        VideoRegression(total_vf_dim=774, regModel="cnnbigru")
+    with pytest.raises(ValueError):
+        VideoRegression(total_vf_dim=774, d_model=256, regModel="bilstm")       # W_hh is held in registers: d_model <= 128
     with pytest.raises(ValueError):
         m, _ = build(dict(n_layers=1, d_model=32, d_hidden=64, total_vf_dim=30, regModel="bimamba+"), seed=0)
         m(torch.zeros(1, 4, 20).cuda(), None, None, torch.zeros(1, 4, 6).cuda())
 
 
-@pytest.mark.parametrize("rm", ["bimamba", "mamba", "mamba+", "moe_bimamba+", "sharedmoe_bimamba+"])
+@pytest.mark.parametrize("rm", ["bimamba", "mamba", "mamba+", "moe_bimamba+", "sharedmoe_bimamba+", "lstm", "bilstm", "gru", "bigru"])
 def test_other_mamba_regmodels_vs_reference_golden(golden, rm):
     g = golden("g_reg.npz")
     m, _ = build(dict(n_layers=2, d_model=32, d_hidden=64, total_vf_dim=30, regModel=rm), seed=5)
@@ -108,6 +110,21 @@ def test_other_mamba_regmodels_vs_reference_golden(golden, rm):
 
 
 def test_unbuilt_regmodels_say_so():
-    for rm in ("bilstm", "gru", "moemamba", "minGRU"):
+    for rm in ("cnngru", "cnnbigru", "moemamba", "minGRU"):
         with pytest.raises(NotImplementedError):
             VideoRegression(total_vf_dim=30, regModel=rm)
+
+
+@pytest.mark.parametrize("rm", ["bilstm", "bigru", "lstm"])
+def test_recurrent_heads_at_deployed_width_vs_oracle(rm):
+    """d_model = 128 (the callers' -d_model_reg): 2 threads per gate row, 64 weights each in registers; 300 frames, 2 clips."""
+    m, sd = build(dict(n_layers=3, d_model=128, d_hidden=256, total_vf_dim=774, regModel=rm), seed=9)
+    rs = np.random.RandomState(2)
+    sem = torch.from_numpy(rs.standard_normal((2, 300, 768)).astype(np.float32))
+    z = rs.standard_normal((2, 300, 6))
+    emo = torch.from_numpy((np.exp(z) / np.exp(z).sum(-1, keepdims=True)).astype(np.float32))
+    ref_ln, ref_inst = R.forward(sd, sem, emo, reg_model=rm)
+    with torch.no_grad():
+        ln_nd, inst = m(sem.cuda(), None, None, emo.cuda())
+    assert ln_nd.shape == (2, 300, 2) and inst.shape == (2, 300, 40)
+    assert (ln_nd.cpu() - ref_ln).abs().max().item() < 1e-4 and (inst.cpu() - ref_inst).abs().max().item() < 1e-4

@@ -105,10 +105,10 @@ class VideoRegression(nn.Module):
     def __init__(self, n_layers=2, d_model=64, d_hidden=1024, dropout=0.1, use_KAN=False, max_sequence_video=300,
                  total_vf_dim=0, regModel="bilstm", scene_embed=False, chord_embed=False):
         super().__init__()
-        if regModel not in ("bimamba+", "bimamba", "mamba", "mamba+", "moe_bimamba+", "sharedmoe_bimamba+"):
+        if regModel not in ("bimamba+", "bimamba", "mamba", "mamba+", "moe_bimamba+", "sharedmoe_bimamba+", "lstm", "bilstm", "gru", "bigru"):
             raise NotImplementedError("built: regModel 'bimamba+' (the callers' default), 'bimamba', 'mamba', 'mamba+', 'moe_bimamba+', "
-                                      "'sharedmoe_bimamba+'; the LSTM / GRU / CNN-GRU / minGRU heads and 'moemamba' (d_state = d_hidden) "
-                                      "of video_regression.py:124-178 are not")
+                                      "'sharedmoe_bimamba+', 'lstm', 'bilstm', 'gru', 'bigru'; the CNN-GRU / minGRU heads and 'moemamba' "
+                                      "(d_state = d_hidden) of video_regression.py:124-178 are not")
         self._version = 1 if regModel.endswith("+") else 0           # MambaConfig.use_version: 1 = the Mamba+ gate
         self._bidirectional = "bimamba" in regModel
         moe = None
@@ -122,15 +122,34 @@ class VideoRegression(nn.Module):
             raise ValueError("d_model and d_hidden must be multiples of 32 (GEMM K step)")
         self.n_layers, self.d_model, self.d_hidden = n_layers, d_model, d_hidden
         self.max_seq_video, self.total_vf_dim, self.regModel = max_sequence_video, total_vf_dim, regModel
-        self.model = (_BiMambaEncoderParams(d_model, d_hidden, n_layers, self._version, moe) if self._bidirectional
-                      else _MambaStackParams(d_model, n_layers))
+        self._rnn = regModel in ("lstm", "bilstm", "gru", "bigru")
+        if self._rnn:
+            # torch's own modules as parameter containers (same keys: weight_ih_l0, ..., *_reverse); their forward is never called
+            if d_model > 128 or d_model % 8:
+                raise ValueError("the recurrent heads keep W_hh in registers: d_model must be a multiple of 8, at most 128")
+            cls = nn.LSTM if "lstm" in regModel else nn.GRU
+            self._dirs = 2 if regModel.startswith("bi") else 1
+            self.model = cls(d_model, d_model, n_layers, bidirectional=self._dirs == 2, dropout=dropout, batch_first=True)
+        else:
+            self.model = (_BiMambaEncoderParams(d_model, d_hidden, n_layers, self._version, moe) if self._bidirectional
+                          else _MambaStackParams(d_model, n_layers))
         self.in_proj = nn.Sequential(nn.Linear(total_vf_dim, d_model), nn.Dropout(dropout))
-        self.regressor = nn.Linear(d_model, 2)
-        self.classifier = nn.Sequential(nn.Linear(d_model, INSTRUMENT_SIZE), nn.Sigmoid())
+        width = d_model * (self._dirs if self._rnn else 1)           # bidirectional recurrent heads: 2 d_model (:201-206)
+        self.regressor = nn.Linear(width, 2)
+        self.classifier = nn.Sequential(nn.Linear(width, INSTRUMENT_SIZE), nn.Sigmoid())
         self._derived_sig = None
 
     # zero-padded copies of the weights whose K (or row count) does not fit the GEMM's steps (rebuilt when they change)
     def _derived(self):
+        if self._rnn:                                   # only the in-projection needs a padded copy
+            w = self.in_proj[0].weight
+            sig = (w.data_ptr(), w._version)
+            if sig != self._derived_sig:
+                self._Fpad = (self.total_vf_dim + 31) // 32 * 32
+                self._Win = torch.zeros(self.d_model, self._Fpad, device=w.device)
+                self._Win[:, :self.total_vf_dim] = w.detach()
+                self._derived_sig = sig
+            return
         blocks = ([m for l in self.model.layers for m in (l.mamba_forward, l.mamba_backward)] if self._bidirectional
                   else [l.mixer for l in self.model.layers])
         ws = [self.in_proj[0].weight] + [m.dt_proj.weight for m in blocks]
@@ -181,6 +200,17 @@ class VideoRegression(nn.Module):
             raise ValueError(f"semantic ({sem.shape[2]}) + emotion ({emo.shape[2]}) features != total_vf_dim ({self.total_vf_dim})")
         vf = ops.concat2(sem.view(B * S, -1), emo.view(B * S, -1), self._Fpad)
         x = ops.linear_ex(vf, self._Win, self.in_proj[0].bias.detach())
+        if self._rnn:                                   # nn.LSTM / nn.GRU (:124-135): per layer and direction, input GEMM + recurrence
+            gates, d = (4 if isinstance(self.model, nn.LSTM) else 3), self.d_model
+            for l in range(self.n_layers):
+                out = torch.empty(B * S, self._dirs * d, device=dev, dtype=torch.float32)
+                for r in range(self._dirs):
+                    sfx = f"_l{l}" + ("_reverse" if r else "")
+                    g = lambda n: getattr(self.model, n + sfx).detach()
+                    xp = ops.linear_ex(x, g("weight_ih"), g("bias_ih"))
+                    ops.rnn_seq(xp, g("weight_hh").contiguous(), g("bias_hh"), out, r * d, B, S, d, gates, reverse=bool(r))
+                x = out
+            return x.view(B, S, self._dirs * d)
         if not self._bidirectional:                     # Mamba.forward (mamba.py:73-78): x = mixer(norm(x)) + x per layer
             for i, lyr in enumerate(self.model.layers):
                 h = ops.rmsnorm(x, lyr.norm.weight.detach(), eps=lyr.norm.eps)
@@ -211,7 +241,7 @@ class VideoRegression(nn.Module):
 
     def forward(self, feature_semantic_list, feature_scene_offset, feature_motion, feature_emotion):
         """-> (loudness_notedensity (B,S,2), instrument (B,S,40)) like video_regression.py:240-245."""
-        out = self.get_feature(feature_semantic_list, feature_scene_offset, feature_motion, feature_emotion)
+        out = self.get_feature(feature_semantic_list, feature_scene_offset, feature_motion, feature_emotion).contiguous()
         B, S, d = out.shape
         rows = out.view(B * S, d)
         ln_nd = ops.linear_ex(rows, self.regressor.weight.detach(), self.regressor.bias.detach())

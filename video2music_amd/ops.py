@@ -137,6 +137,13 @@ def dwconv1d_silu(xz, C_, w, bias, B, L, reverse=False):
     return y
 
 
+def rnn_seq(xproj, w_hh, b_hh, y, col, B, L, d, gates, reverse=False):
+    """One layer / direction of nn.LSTM (gates=4) or nn.GRU (gates=3) over projected inputs xproj (B*L, gates*d); h_t goes to
+    columns [col, col+d) of y (B*L, ldy)."""
+    _lib.call("amt_rnn_seq_fwd", p(xproj), xproj.shape[1], p(w_hh), p(b_hh), _off(y, col), y.shape[1], B, L, d, gates, int(reverse), _st())
+    return y
+
+
 def selective_scan(xc, draw, dt_bias, A_log, dbc, R, D, xz, B, L, version=1, reverse=False):
     """Selective scan + gate.  xc, draw (B*L, ED); dbc (B*L, R+2N) = x_proj output (B at column R, C at R+N);
     xz (B*L, 2*ED) = in_proj output (gate branch z at column ED)."""
