@@ -253,9 +253,11 @@ int32_t amt_v2_step(const void* const* tab, int32_t n_layers, int32_t H, int32_t
  * The recurrence of one layer and direction over projected inputs xproj (B, L, ldxp) whose columns [0, gates*d) hold
  * W_ih x + b_ih (gate order of torch: LSTM i,f,g,o; GRU r,z,n): gates = 4 LSTM, 3 GRU; w_hh (gates*d, d), b_hh (gates*d);
  * y (B, L, ldy) receives h_t in columns [0, d) of the pointer given (pass y + d for the reverse direction of a
- * bidirectional layer); reverse = 1 walks t = L-1 .. 0 and writes h at t.  d a multiple of 8, at most 128. */
+ * bidirectional layer); reverse = 1 walks t = L-1 .. 0 and writes h at t.  d a multiple of 8, at most 128.
+ * n_dirs = 2 runs both directions of a bidirectional layer in one launch: xproj then holds [forward | reverse] projections
+ * side by side (2*gates*d columns), w_hh / b_hh the two directions stacked, y gets [h_forward | h_reverse] (2*d columns). */
 int32_t amt_rnn_seq_fwd(const float* xproj, int32_t ldxp, const float* w_hh, const float* b_hh, float* y, int32_t ldy,
-                        int32_t B, int32_t L, int32_t d, int32_t gates, int32_t reverse, void* stream);
+                        int32_t B, int32_t L, int32_t d, int32_t gates, int32_t reverse, int32_t n_dirs, void* stream);
 
 /* The same step for B independent clips in lockstep (all at one position): projections are one launch over B rows (weights
  * read once per step, not once per clip), the caches carry a leading clip dimension (self K/V: B, H, max_seq, hd; cross K/V:

@@ -75,7 +75,7 @@ SIGNATURES = {
     "amt_v2_step_ws_floats": [_I, _I, _I],
     "amt_pack_weight_fwd": [_P, _P, _I, _I, _P],
     "amt_v2_step": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P],
-    "amt_rnn_seq_fwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "amt_rnn_seq_fwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "amt_v2_step_batch_ws_floats": [_I, _I, _I, _I],
     "amt_v2_step_batch": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
 }

@@ -22,6 +22,8 @@ constexpr int MAXD = 128;               // hidden size limit: d/2 weights per th
 
 // xp: [B][L][ldxp] projected inputs of this direction (columns [0, G*d): W_ih x + b_ih); whh [G*d][d]; bhh [G*d];
 // y: [B][L][ldy], this direction writes columns [0, d) of its y pointer.  reverse: walk t = L-1 .. 0.
+// gridDim.y == 2 (both directions of a bidirectional layer at once): direction dir = blockIdx.y reads columns
+// [dir*G*d, (dir+1)*G*d) of xp, the dir-th of the stacked whh / bhh, writes columns [dir*d, (dir+1)*d) of y; dir 1 walks backwards.
 template <int G>
 __global__ __launch_bounds__(2 * 4 * MAXD) void rnn_seq_kernel(const float* __restrict__ xp, int ldxp, const float* __restrict__ whh,
                                                                const float* __restrict__ bhh, float* __restrict__ y, int ldy,
@@ -30,6 +32,10 @@ __global__ __launch_bounds__(2 * 4 * MAXD) void rnn_seq_kernel(const float* __re
     __shared__ float sa[4 * MAXD];                                  // W_hh h + b_hh per gate row
     const int tid = threadIdx.x, b = blockIdx.x;
     const int row = tid >> 1, half = tid & 1, R = G * d, hc = d >> 1;
+    if (gridDim.y == 2) {
+        const int dir = blockIdx.y;
+        xp += dir * R; whh += (size_t)dir * R * d; bhh += dir * R; y += dir * d; reverse = dir;
+    }
     // this thread's half row of W_hh
     float w[MAXD / 2];
 #pragma unroll
@@ -83,15 +89,16 @@ __global__ __launch_bounds__(2 * 4 * MAXD) void rnn_seq_kernel(const float* __re
 }  // namespace
 
 extern "C" int32_t amt_rnn_seq_fwd(const float* xproj, int32_t ldxp, const float* w_hh, const float* b_hh, float* y, int32_t ldy,
-                                   int32_t B, int32_t L, int32_t d, int32_t gates, int32_t reverse, void* stream) {
+                                   int32_t B, int32_t L, int32_t d, int32_t gates, int32_t reverse, int32_t n_dirs, void* stream) {
     AMT_CHECK_ARG(xproj && w_hh && b_hh && y, "amt_rnn_seq_fwd: null pointer");
     AMT_CHECK_ARG(gates == 3 || gates == 4, "amt_rnn_seq_fwd: gates=%d (4 = LSTM, 3 = GRU)", gates);
     AMT_CHECK_ARG(B > 0 && L > 0 && d >= 8 && d <= MAXD && d % 8 == 0, "amt_rnn_seq_fwd: hidden size %d must be a multiple of 8, at most %d", d, MAXD);
-    AMT_CHECK_ARG(ldxp >= gates * d && ldy >= d, "amt_rnn_seq_fwd: bad leading dimensions");
+    AMT_CHECK_ARG(n_dirs == 1 || n_dirs == 2, "amt_rnn_seq_fwd: n_dirs=%d", n_dirs);
+    AMT_CHECK_ARG(ldxp >= n_dirs * gates * d && ldy >= n_dirs * d, "amt_rnn_seq_fwd: bad leading dimensions");
     hipStream_t s = (hipStream_t)stream;
     const int threads = 2 * gates * d;                       // two threads per gate row
-    if (gates == 4) hipLaunchKernelGGL(rnn_seq_kernel<4>, dim3(B), dim3(threads), 0, s, xproj, ldxp, w_hh, b_hh, y, ldy, L, d, reverse);
-    else hipLaunchKernelGGL(rnn_seq_kernel<3>, dim3(B), dim3(threads), 0, s, xproj, ldxp, w_hh, b_hh, y, ldy, L, d, reverse);
+    if (gates == 4) hipLaunchKernelGGL(rnn_seq_kernel<4>, dim3(B, n_dirs), dim3(threads), 0, s, xproj, ldxp, w_hh, b_hh, y, ldy, L, d, reverse);
+    else hipLaunchKernelGGL(rnn_seq_kernel<3>, dim3(B, n_dirs), dim3(threads), 0, s, xproj, ldxp, w_hh, b_hh, y, ldy, L, d, reverse);
     AMT_LAUNCH_CHECK();
     return 0;
 }

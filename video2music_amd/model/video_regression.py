@@ -173,6 +173,18 @@ class VideoRegression(nn.Module):
                 self._Wx.append(t)
             self._derived_sig = sig
 
+    def _rnn_layer(self, l):
+        """(W_ih, b_ih, W_hh, b_hh) of layer l with the directions stacked along the rows; rebuilt when a parameter changes."""
+        names = [n + f"_l{l}" + sfx for sfx in (("", "_reverse") if self._dirs == 2 else ("",))
+                 for n in ("weight_ih", "bias_ih", "weight_hh", "bias_hh")]
+        ps = [getattr(self.model, n) for n in names]
+        sig = tuple((q.data_ptr(), q._version) for q in ps)
+        cache = self.__dict__.setdefault("_rnn_cache", {})
+        if cache.get(l, (None,))[0] != sig:
+            per = [[q.detach() for q in ps[4 * r:4 * r + 4]] for r in range(self._dirs)]
+            cache[l] = (sig, tuple(torch.cat([per[r][k] for r in range(self._dirs)]).contiguous() for k in range(4)))
+        return cache[l][1]
+
     def _mamba(self, x, m, wdt, wx, B, L, resid, reverse):
         """MambaBlock.forward on rows x (B*L, d) + the layer's residual add (out_proj epilogue)."""
         R, N = m.dt_rank, m.d_state
@@ -202,13 +214,10 @@ class VideoRegression(nn.Module):
         x = ops.linear_ex(vf, self._Win, self.in_proj[0].bias.detach())
         if self._rnn:                                   # nn.LSTM / nn.GRU (:124-135): per layer and direction, input GEMM + recurrence
             gates, d = (4 if isinstance(self.model, nn.LSTM) else 3), self.d_model
-            for l in range(self.n_layers):
+            for l in range(self.n_layers):               # both directions: one input GEMM, one recurrence launch
+                wi, bi, wh, bh = self._rnn_layer(l)
                 out = torch.empty(B * S, self._dirs * d, device=dev, dtype=torch.float32)
-                for r in range(self._dirs):
-                    sfx = f"_l{l}" + ("_reverse" if r else "")
-                    g = lambda n: getattr(self.model, n + sfx).detach()
-                    xp = ops.linear_ex(x, g("weight_ih"), g("bias_ih"))
-                    ops.rnn_seq(xp, g("weight_hh").contiguous(), g("bias_hh"), out, r * d, B, S, d, gates, reverse=bool(r))
+                ops.rnn_seq(ops.linear_ex(x, wi, bi), wh, bh, out, 0, B, S, d, gates, n_dirs=self._dirs)
                 x = out
             return x.view(B, S, self._dirs * d)
         if not self._bidirectional:                     # Mamba.forward (mamba.py:73-78): x = mixer(norm(x)) + x per layer

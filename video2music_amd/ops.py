@@ -137,10 +137,11 @@ def dwconv1d_silu(xz, C_, w, bias, B, L, reverse=False):
     return y
 
 
-def rnn_seq(xproj, w_hh, b_hh, y, col, B, L, d, gates, reverse=False):
-    """One layer / direction of nn.LSTM (gates=4) or nn.GRU (gates=3) over projected inputs xproj (B*L, gates*d); h_t goes to
-    columns [col, col+d) of y (B*L, ldy)."""
-    _lib.call("amt_rnn_seq_fwd", p(xproj), xproj.shape[1], p(w_hh), p(b_hh), _off(y, col), y.shape[1], B, L, d, gates, int(reverse), _st())
+def rnn_seq(xproj, w_hh, b_hh, y, col, B, L, d, gates, reverse=False, n_dirs=1):
+    """One layer of nn.LSTM (gates=4) or nn.GRU (gates=3) over projected inputs xproj (B*L, n_dirs*gates*d); h_t goes to columns
+    [col, col + n_dirs*d) of y (B*L, ldy).  n_dirs=2: both directions at once over stacked w_hh (2, gates*d, d) / b_hh."""
+    _lib.call("amt_rnn_seq_fwd", p(xproj), xproj.shape[1], p(w_hh), p(b_hh), _off(y, col), y.shape[1], B, L, d, gates, int(reverse),
+              n_dirs, _st())
     return y
 
 
