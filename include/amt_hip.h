@@ -288,7 +288,8 @@ int32_t amt_selective_scan_fwd(const float* x, int32_t ldx, const float* delta_r
 int32_t amt_concat2_fwd(const float* a, int32_t da, const float* b, int32_t db, float* out, int32_t rows, int32_t ld_out,
                         void* stream);
 /* amt_linear_fwd with leading dimensions and an activation: y = act(x[M,K](ldx) . w[N,K](ldw)^T + bias (+ resid(ldr)));
- * act 0 none, 1 ReLU, 2 sigmoid (the classifier head, video_regression.py:188-197).  K % 32 == 0. */
+ * act 0 none, 1 ReLU, 2 sigmoid (the classifier head, video_regression.py:188-197), 3 SiLU (CNN_GRU's convolution, :88-91).
+ * K % 32 == 0. */
 int32_t amt_linear_ex_fwd(const float* x, int32_t ldx, const float* w, int32_t ldw, const float* bias, const float* resid,
                           int32_t ldr, float* y, int32_t ldy, int32_t M, int32_t N, int32_t K, int32_t act, void* stream);
 /* y = LayerNorm(x (+ resid)) + post : the "norm2(x_b + x) then x_f + x_b" step of bimamba.py:183-188 in one pass. */

@@ -119,14 +119,20 @@ def residual_block(x, sd, p, version):
 def rnn_stack(x, sd, kind, bidirectional):
     """torch.nn.LSTM / nn.GRU, batch_first, eval (the reference builds them at video_regression.py:124-135; the cell
     equations are torch's documented ones).  x (B, L, d); keys model.weight_ih_l{k}[_reverse] etc.; gate order i,f,g,o / r,z,n."""
+    pre = "model.gru." if "model.gru.weight_ih_l0" in sd else "model."
+    if pre == "model.gru.":                 # CNN_GRU (video_regression.py:84-103): Conv1d(k=7, padding=3) over time + SiLU first
+        W, bc = sd["model.cnn.0.weight"], sd["model.cnn.0.bias"]
+        K = W.shape[2]
+        xp = F.pad(x, (0, 0, K // 2, K // 2))
+        x = F.silu(sum(xp[:, j:j + x.shape[1]] @ W[:, :, j].t() for j in range(K)) + bc)
     n = 0
-    while f"model.weight_ih_l{n}" in sd:
+    while f"{pre}weight_ih_l{n}" in sd:
         n += 1
     for l in range(n):
         outs = []
         for rev in ([False, True] if bidirectional else [False]):
             sfx = f"_l{l}" + ("_reverse" if rev else "")
-            Wi, Wh, bi, bh = (sd[f"model.{k}{sfx}"] for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+            Wi, Wh, bi, bh = (sd[f"{pre}{k}{sfx}"] for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
             d = Wh.shape[1]
             B, L, _ = x.shape
             h, c = torch.zeros(B, d, dtype=x.dtype), torch.zeros(B, d, dtype=x.dtype)
@@ -159,9 +165,10 @@ def forward(sd, sem, emotion, collect=None, reg_model="bimamba+"):
     x = linear(vf, sd["in_proj.0.weight"], sd["in_proj.0.bias"])
     if collect is not None:
         collect["in_proj"] = x
-    if reg_model in ("lstm", "bilstm", "gru", "bigru"):
-        x = rnn_stack(x, sd, "lstm" if "lstm" in reg_model else "gru", reg_model.startswith("bi"))
-    for l in range(0 if reg_model in ("lstm", "bilstm", "gru", "bigru") else n_layers_of(sd)):
+    rnn = reg_model in ("lstm", "bilstm", "gru", "bigru", "cnngru", "cnnbigru")
+    if rnn:
+        x = rnn_stack(x, sd, "lstm" if "lstm" in reg_model else "gru", "bi" in reg_model)
+    for l in range(0 if rnn else n_layers_of(sd)):
         p = f"model.layers.{l}."
         if reg_model.startswith("bi"):
             x = bimamba_layer(x, sd, p, 1) if version == 1 else bimamba_layer_v0(x, sd, p)

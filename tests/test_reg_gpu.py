@@ -90,7 +90,7 @@ def test_deployed_size_vs_oracle_and_postprocessing():
 
 def test_rejects_unbuilt_variants():
     with pytest.raises(NotImplementedError):
-        VideoRegression(total_vf_dim=774, regModel="cnnbigru")
+        VideoRegression(total_vf_dim=774, regModel="minGRU")
     with pytest.raises(ValueError):
         VideoRegression(total_vf_dim=774, d_model=256, regModel="bilstm")       # W_hh is held in registers: d_model <= 128
     with pytest.raises(ValueError):
@@ -98,7 +98,7 @@ def test_rejects_unbuilt_variants():
         m(torch.zeros(1, 4, 20).cuda(), None, None, torch.zeros(1, 4, 6).cuda())
 
 
-@pytest.mark.parametrize("rm", ["bimamba", "mamba", "mamba+", "moe_bimamba+", "sharedmoe_bimamba+", "lstm", "bilstm", "gru", "bigru"])
+@pytest.mark.parametrize("rm", ["bimamba", "mamba", "mamba+", "moe_bimamba+", "sharedmoe_bimamba+", "lstm", "bilstm", "gru", "bigru", "cnngru", "cnnbigru"])
 def test_other_mamba_regmodels_vs_reference_golden(golden, rm):
     g = golden("g_reg.npz")
     m, _ = build(dict(n_layers=2, d_model=32, d_hidden=64, total_vf_dim=30, regModel=rm), seed=5)
@@ -110,12 +110,12 @@ def test_other_mamba_regmodels_vs_reference_golden(golden, rm):
 
 
 def test_unbuilt_regmodels_say_so():
-    for rm in ("cnngru", "cnnbigru", "moemamba", "minGRU"):
+    for rm in ("moemamba", "minGRU"):
         with pytest.raises(NotImplementedError):
             VideoRegression(total_vf_dim=30, regModel=rm)
 
 
-@pytest.mark.parametrize("rm", ["bilstm", "bigru", "lstm"])
+@pytest.mark.parametrize("rm", ["bilstm", "bigru", "lstm", "cnnbigru"])
 def test_recurrent_heads_at_deployed_width_vs_oracle(rm):
     """d_model = 128 (the callers' -d_model_reg): 2 threads per gate row, 64 weights each in registers; 300 frames, 2 clips."""
     m, sd = build(dict(n_layers=3, d_model=128, d_hidden=256, total_vf_dim=774, regModel=rm), seed=9)

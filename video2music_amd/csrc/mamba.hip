@@ -184,9 +184,9 @@ extern "C" int32_t amt_concat2_fwd(const float* a, int32_t da, const float* b, i
 extern "C" int32_t amt_linear_ex_fwd(const float* x, int32_t ldx, const float* w, int32_t ldw, const float* bias, const float* resid,
                                      int32_t ldr, float* y, int32_t ldy, int32_t M, int32_t N, int32_t K, int32_t act, void* stream) {
     AMT_CHECK_ARG(x && w && y, "amt_linear_ex_fwd: null pointer");
-    AMT_CHECK_ARG(act >= 0 && act <= 2, "amt_linear_ex_fwd: act %d not in {0 none, 1 relu, 2 sigmoid}", act);
+    AMT_CHECK_ARG(act >= 0 && act <= 3, "amt_linear_ex_fwd: act %d not in {0 none, 1 relu, 2 sigmoid, 3 silu}", act);
     GemmParams g = gemm_params(x, ldx, w, ldw, y, ldy, M, N, K, bias);
-    g.resid = resid; g.ldr = ldr; g.relu = act == 1; g.sigmoid = act == 2;
+    g.resid = resid; g.ldr = ldr; g.relu = act == 1 ? 1 : (act == 3 ? 2 : 0); g.sigmoid = act == 2;
     return amt_launch_gemm(g, (hipStream_t)stream);
 }
 

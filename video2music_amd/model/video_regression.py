@@ -1,7 +1,9 @@
 """`VideoRegression` (reference model/video_regression.py:104-245) for the Mamba regModels: 'bimamba+' -- the default
 regression head of both callers (utilities/argument_generate_funcs.py:87-91, video2music.py:651) --, 'bimamba' (the same
 encoder over the original Mamba gate), and the one-directional stacks 'mamba' / 'mamba+' (mamba.py:66-100,131-147:
-x + MambaBlock(RMSNorm(x)) per layer).  Per video frame it predicts (note density, loudness) and 40 instrument
+x + MambaBlock(RMSNorm(x)) per layer), 'moe_bimamba+' / 'sharedmoe_bimamba+' (a mixture layer in the FFN's place), and the
+recurrent heads 'lstm' / 'bilstm' / 'gru' / 'bigru' / 'cnngru' / 'cnnbigru' (torch's nn.LSTM / nn.GRU, kept as parameter
+containers; the recurrence runs in csrc/rnn.hip).  Per video frame it predicts (note density, loudness) and 40 instrument
 probabilities from cat(semantic, emotion) — SURVEY.md §8 row f2.
 
 The module keeps the reference's parameter names (so `load_state_dict(torch.load(path))` works) and composes the
@@ -12,6 +14,7 @@ library's kernels; no torch arithmetic runs in `forward`:
     Conv1d + SiLU             amt_dwconv1d_silu_fwd
     softplus, scan, gate      amt_selective_scan_fwd
     LayerNorms                amt_layernorm_post_fwd (residual in, `x_f + x_b` out)
+    LSTM / GRU recurrence     amt_rnn_seq_fwd (both directions of a layer in one launch)
 
 The backward Mamba block runs with `reverse=1` instead of `torch.flip` before and after (bimamba.py:171-185).
 """
@@ -105,9 +108,10 @@ class VideoRegression(nn.Module):
     def __init__(self, n_layers=2, d_model=64, d_hidden=1024, dropout=0.1, use_KAN=False, max_sequence_video=300,
                  total_vf_dim=0, regModel="bilstm", scene_embed=False, chord_embed=False):
         super().__init__()
-        if regModel not in ("bimamba+", "bimamba", "mamba", "mamba+", "moe_bimamba+", "sharedmoe_bimamba+", "lstm", "bilstm", "gru", "bigru"):
+        if regModel not in ("bimamba+", "bimamba", "mamba", "mamba+", "moe_bimamba+", "sharedmoe_bimamba+", "lstm", "bilstm", "gru", "bigru",
+                            "cnngru", "cnnbigru"):
             raise NotImplementedError("built: regModel 'bimamba+' (the callers' default), 'bimamba', 'mamba', 'mamba+', 'moe_bimamba+', "
-                                      "'sharedmoe_bimamba+', 'lstm', 'bilstm', 'gru', 'bigru'; the CNN-GRU / minGRU heads and 'moemamba' "
+                                      "'sharedmoe_bimamba+', 'lstm', 'bilstm', 'gru', 'bigru', 'cnngru', 'cnnbigru'; 'minGRU' and 'moemamba' "
                                       "(d_state = d_hidden) of video_regression.py:124-178 are not")
         self._version = 1 if regModel.endswith("+") else 0           # MambaConfig.use_version: 1 = the Mamba+ gate
         self._bidirectional = "bimamba" in regModel
@@ -122,14 +126,21 @@ class VideoRegression(nn.Module):
             raise ValueError("d_model and d_hidden must be multiples of 32 (GEMM K step)")
         self.n_layers, self.d_model, self.d_hidden = n_layers, d_model, d_hidden
         self.max_seq_video, self.total_vf_dim, self.regModel = max_sequence_video, total_vf_dim, regModel
-        self._rnn = regModel in ("lstm", "bilstm", "gru", "bigru")
+        self._rnn = regModel in ("lstm", "bilstm", "gru", "bigru", "cnngru", "cnnbigru")
         if self._rnn:
             # torch's own modules as parameter containers (same keys: weight_ih_l0, ..., *_reverse); their forward is never called
             if d_model > 128 or d_model % 8:
                 raise ValueError("the recurrent heads keep W_hh in registers: d_model must be a multiple of 8, at most 128")
             cls = nn.LSTM if "lstm" in regModel else nn.GRU
-            self._dirs = 2 if regModel.startswith("bi") else 1
-            self.model = cls(d_model, d_model, n_layers, bidirectional=self._dirs == 2, dropout=dropout, batch_first=True)
+            self._dirs = 2 if "bi" in regModel else 1
+            rnn = cls(d_model, d_model, n_layers, bidirectional=self._dirs == 2, dropout=dropout, batch_first=True)
+            if regModel.startswith("cnn"):                # CNN_GRU (:84-103): Conv1d(k=7, pad=3) + SiLU, then the GRU
+                self.model = nn.Module()
+                self.model.cnn = nn.Sequential(nn.Conv1d(d_model, d_model, kernel_size=7, stride=1, padding=3), nn.SiLU(), nn.Dropout(dropout))
+                self.model.gru = rnn
+            else:
+                self.model = rnn
+            self.__dict__["_rnn_mod"] = rnn          # an alias outside the module registry (no second set of keys)
         else:
             self.model = (_BiMambaEncoderParams(d_model, d_hidden, n_layers, self._version, moe) if self._bidirectional
                           else _MambaStackParams(d_model, n_layers))
@@ -173,11 +184,30 @@ class VideoRegression(nn.Module):
                 self._Wx.append(t)
             self._derived_sig = sig
 
+    def _conv7_silu(self, x, B, S):
+        """CNN_GRU's Conv1d(d, d, kernel 7, padding 3) + SiLU over time (:88-91, :97-100) as seven accumulating GEMMs: the clips
+        are laid end to end with 3 zero frames on each side, tap j of output row r reads row r + j; the SiLU rides on the last one."""
+        conv = self.model.cnn[0]
+        d, K = self.d_model, conv.kernel_size[0]
+        pad = K // 2
+        W = conv.weight.detach()                                   # (d_out, d_in, K)
+        xp = torch.zeros(B, S + 2 * pad, d, device=x.device, dtype=torch.float32)
+        xp[:, pad:pad + S] = x.view(B, S, d)
+        flat = xp.view(B * (S + 2 * pad), d)
+        M = flat.shape[0] - 2 * pad
+        acc = None
+        for j in range(K):
+            acc = ops.linear_ex(flat[j:j + M], W[:, :, j].contiguous(), conv.bias.detach() if j == 0 else None, resid=acc,
+                                act=3 if j == K - 1 else 0)
+        out = torch.zeros(B, S + 2 * pad, d, device=x.device, dtype=torch.float32)
+        out.view(-1, d)[:M] = acc
+        return out[:, :S].contiguous().view(B * S, d)
+
     def _rnn_layer(self, l):
         """(W_ih, b_ih, W_hh, b_hh) of layer l with the directions stacked along the rows; rebuilt when a parameter changes."""
         names = [n + f"_l{l}" + sfx for sfx in (("", "_reverse") if self._dirs == 2 else ("",))
                  for n in ("weight_ih", "bias_ih", "weight_hh", "bias_hh")]
-        ps = [getattr(self.model, n) for n in names]
+        ps = [getattr(self._rnn_mod, n) for n in names]
         sig = tuple((q.data_ptr(), q._version) for q in ps)
         cache = self.__dict__.setdefault("_rnn_cache", {})
         if cache.get(l, (None,))[0] != sig:
@@ -213,7 +243,9 @@ class VideoRegression(nn.Module):
         vf = ops.concat2(sem.view(B * S, -1), emo.view(B * S, -1), self._Fpad)
         x = ops.linear_ex(vf, self._Win, self.in_proj[0].bias.detach())
         if self._rnn:                                   # nn.LSTM / nn.GRU (:124-135): per layer and direction, input GEMM + recurrence
-            gates, d = (4 if isinstance(self.model, nn.LSTM) else 3), self.d_model
+            gates, d = (4 if isinstance(self._rnn_mod, nn.LSTM) else 3), self.d_model
+            if self._rnn_mod is not self.model:
+                x = self._conv7_silu(x, B, S)
             for l in range(self.n_layers):               # both directions: one input GEMM, one recurrence launch
                 wi, bi, wh, bh = self._rnn_layer(l)
                 out = torch.empty(B * S, self._dirs * d, device=dev, dtype=torch.float32)

@@ -105,7 +105,7 @@ def _off(t, col):
 
 
 def linear_ex(x, w, b=None, resid=None, act=0, x_col=0, K=None, out=None):
-    """y = act(x[:, x_col:x_col+K] w[N,K]^T + b (+ resid)); act 0 none / 1 ReLU / 2 sigmoid.  K % 32 == 0."""
+    """y = act(x[:, x_col:x_col+K] w[N,K]^T + b (+ resid)); act 0 none / 1 ReLU / 2 sigmoid / 3 SiLU.  K % 32 == 0."""
     M, ldx = x.shape
     N, ldw = w.shape
     K = ldw if K is None else K
