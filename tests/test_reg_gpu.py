@@ -128,3 +128,42 @@ def test_recurrent_heads_at_deployed_width_vs_oracle(rm):
         ln_nd, inst = m(sem.cuda(), None, None, emo.cuda())
     assert ln_nd.shape == (2, 300, 2) and inst.shape == (2, 300, 40)
     assert (ln_nd.cpu() - ref_ln).abs().max().item() < 1e-4 and (inst.cpu() - ref_inst).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("gates", [3, 4])
+def test_rnn_seq_kernel_shapes_vs_cell_equations(gates):
+    """Operator-level: hidden sizes 8..128, one-step and ragged lengths, one direction (forward / backward) and both at once,
+    against the cell equations in fp64."""
+    gen = torch.Generator().manual_seed(gates)
+    for (B, L, d, dirs) in ((1, 1, 8, 1), (3, 2, 16, 2), (2, 77, 64, 2), (1, 300, 128, 2), (2, 5, 128, 1), (1, 33, 40, 2)):
+        G = gates * d
+        xp = torch.randn(B * L, dirs * G, generator=gen)
+        wh, bh = torch.randn(dirs, G, d, generator=gen) * (1.0 / d ** 0.5), torch.randn(dirs, G, generator=gen) * 0.1
+
+        def cell(xrow, h, c, r):
+            gx, gh = xrow.double(), h @ wh[r].double().t() + bh[r].double()
+            if gates == 4:
+                i, f, g, o = (gx + gh).chunk(4, -1)
+                c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+                return torch.sigmoid(o) * torch.tanh(c), c
+            xr, xz, xn = gx.chunk(3, -1)
+            hr, hz, hn = gh.chunk(3, -1)
+            rr, z = torch.sigmoid(xr + hr), torch.sigmoid(xz + hz)
+            return (1 - z) * torch.tanh(xn + rr * hn) + z * h, c
+
+        ref = torch.zeros(B, L, dirs * d, dtype=torch.float64)
+        x3 = xp.view(B, L, dirs * G)
+        for r in range(dirs):
+            h, c = torch.zeros(B, d, dtype=torch.float64), torch.zeros(B, d, dtype=torch.float64)
+            for t in (range(L - 1, -1, -1) if r else range(L)):
+                h, c = cell(x3[:, t, r * G:(r + 1) * G], h, c, r)
+                ref[:, t, r * d:(r + 1) * d] = h
+        y = torch.full((B * L, dirs * d), float("nan")).cuda()
+        ops.rnn_seq(xp.cuda(), wh.cuda().contiguous(), bh.cuda().contiguous(), y, 0, B, L, d, gates, n_dirs=dirs)
+        assert (y.cpu().double().view(B, L, dirs * d) - ref).abs().max().item() < 2e-5, (B, L, d, dirs)
+        if dirs == 2:       # each direction alone, through the single-direction form, writes the same columns
+            y1 = torch.full((B * L, 2 * d), float("nan")).cuda()
+            for r in range(2):
+                ops.rnn_seq(xp[:, r * G:(r + 1) * G].contiguous().cuda(), wh[r].cuda().contiguous(), bh[r].cuda().contiguous(), y1, r * d, B, L, d,
+                            gates, reverse=bool(r))
+            assert torch.equal(y1, y)
