@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from video2music_amd import synthetic
 from video2music_amd.model.video_music_transformer import VideoMusicTransformer_V2
-nb = int(os.environ.get("NB", "16"))
+nb = int(os.environ.get("NB", "32"))
 cfg = dict(version_name="2.2", n_layers=6, num_heads=8, d_model=512, dim_feedforward=1024, max_sequence_chord=300, total_vf_dim=1287)
 m = VideoMusicTransformer_V2(**cfg).eval()
 shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
