@@ -54,7 +54,7 @@ def main():
     z = rs.standard_normal((3, 50, 6))
     emo = torch.from_numpy((np.exp(z) / np.exp(z).sum(-1, keepdims=True)).astype(np.float32))
     out["alt_sem"], out["alt_emo"] = sem.numpy(), emo.numpy()
-    for rm in ("bimamba", "mamba", "mamba+", "moe_bimamba+", "sharedmoe_bimamba+", "lstm", "bilstm", "gru", "bigru", "cnngru", "cnnbigru"):
+    for rm in ("bimamba", "mamba", "mamba+", "moe_bimamba+", "sharedmoe_bimamba+", "lstm", "bilstm", "gru", "bigru", "cnngru", "cnnbigru", "moemamba"):
         mm = VideoRegression(max_sequence_video=300, **dict(CFG, regModel=rm)).eval()
         shp = [(k, tuple(v.shape)) for k, v in mm.state_dict().items()]
         mm.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shp, seed=5).items()}, strict=True)

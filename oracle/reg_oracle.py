@@ -105,7 +105,7 @@ def bimamba_layer_v0(x, sd, p):
 
 def n_layers_of(sd):
     n = 0
-    while f"model.layers.{n}.norm1.weight" in sd or f"model.layers.{n}.norm.weight" in sd:
+    while any(f"model.layers.{n}.{k}" in sd for k in ("norm1.weight", "norm.weight", "0.norm.weight")):
         n += 1
     return n
 
@@ -159,7 +159,7 @@ def forward(sd, sem, emotion, collect=None, reg_model="bimamba+"):
     Scene offset and motion are accepted by the reference's signature but not used (:205-213 are commented out).
     reg_model: 'bimamba+' / 'bimamba' (BiMambaEncoder) or 'mamba+' / 'mamba' (Mamba stack); '+' = use_version 1."""
     version = 1 if reg_model.endswith("+") else 0
-    reg_model = reg_model.replace("sharedmoe_", "").replace("moe_", "")       # same layers; the mixture shows in the keys
+    reg_model = reg_model.replace("sharedmoe_", "").replace("moe_", "").replace("moemamba", "mamba")   # the mixture shows in the keys
     sd = {k: v.float() for k, v in sd.items()}
     vf = torch.cat([sem.float(), emotion.float()], dim=-1)
     x = linear(vf, sd["in_proj.0.weight"], sd["in_proj.0.bias"])
@@ -170,7 +170,13 @@ def forward(sd, sem, emotion, collect=None, reg_model="bimamba+"):
         x = rnn_stack(x, sd, "lstm" if "lstm" in reg_model else "gru", "bi" in reg_model)
     for l in range(0 if rnn else n_layers_of(sd)):
         p = f"model.layers.{l}."
-        if reg_model.startswith("bi"):
+        if reg_model == "mamba" and p + "0.norm.weight" in sd:          # MoEMamba (mamba.py:102-129): ResidualBlock, then ResidualMoE
+            from oracle.amt_oracle import moe_forward
+            x = residual_block(x, sd, p + "0.", 0)
+            h = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * sd[p + "1.norm.weight"]
+            sub = {k[len(p) + 12:]: v for k, v in sd.items() if k.startswith(p + "1.moe_layer.")}
+            x = moe_forward(h, sub, sub["gate.weight"].shape[0], k=2, shared=True) + x
+        elif reg_model.startswith("bi"):
             x = bimamba_layer(x, sd, p, 1) if version == 1 else bimamba_layer_v0(x, sd, p)
         else:
             x = residual_block(x, sd, p, version)

@@ -98,7 +98,7 @@ def test_rejects_unbuilt_variants():
         m(torch.zeros(1, 4, 20).cuda(), None, None, torch.zeros(1, 4, 6).cuda())
 
 
-@pytest.mark.parametrize("rm", ["bimamba", "mamba", "mamba+", "moe_bimamba+", "sharedmoe_bimamba+", "lstm", "bilstm", "gru", "bigru", "cnngru", "cnnbigru"])
+@pytest.mark.parametrize("rm", ["bimamba", "mamba", "mamba+", "moe_bimamba+", "sharedmoe_bimamba+", "lstm", "bilstm", "gru", "bigru", "cnngru", "cnnbigru", "moemamba"])
 def test_other_mamba_regmodels_vs_reference_golden(golden, rm):
     g = golden("g_reg.npz")
     m, _ = build(dict(n_layers=2, d_model=32, d_hidden=64, total_vf_dim=30, regModel=rm), seed=5)
@@ -110,7 +110,7 @@ def test_other_mamba_regmodels_vs_reference_golden(golden, rm):
 
 
 def test_unbuilt_regmodels_say_so():
-    for rm in ("moemamba", "minGRU"):
+    for rm in ("minGRU",):
         with pytest.raises(NotImplementedError):
             VideoRegression(total_vf_dim=30, regModel=rm)
 
@@ -167,3 +167,27 @@ def test_rnn_seq_kernel_shapes_vs_cell_equations(gates):
                 ops.rnn_seq(xp[:, r * G:(r + 1) * G].contiguous().cuda(), wh[r].cuda().contiguous(), bh[r].cuda().contiguous(), y1, r * d, B, L, d,
                             gates, reverse=bool(r))
             assert torch.equal(y1, y)
+
+
+def test_wide_state_scan_vs_oracle():
+    """The scan with N = 32 .. 256 states per channel ('moemamba': d_state = d_hidden), both directions and gate versions."""
+    gen = torch.Generator().manual_seed(3)
+    for (B, L, ED, N) in ((1, 5, 16, 32), (2, 40, 24, 64), (1, 77, 64, 128), (2, 300, 64, 256)):
+        rk = 4
+        xc = torch.randn(B * L, ED, generator=gen)
+        xz = torch.randn(B * L, 2 * ED, generator=gen)
+        dbc = torch.randn(B * L, (rk + 2 * N + 3) // 4 * 4, generator=gen) * 0.5
+        draw = torch.randn(B * L, ED, generator=gen)
+        dtb, A_log, D = torch.randn(ED, generator=gen), torch.randn(ED, N, generator=gen) * 0.5, torch.randn(ED, generator=gen)
+        for reverse in (False, True):
+            for version in (0, 1):
+                x3, d3 = xc.view(B, L, ED).double(), torch.nn.functional.softplus(draw.view(B, L, ED).double() + dtb.double())
+                Bm, Cm = dbc.view(B, L, -1)[..., rk:rk + N].double(), dbc.view(B, L, -1)[..., rk + N:rk + 2 * N].double()
+                flip = (lambda t: torch.flip(t, dims=[1])) if reverse else (lambda t: t)
+                y = flip(R.selective_scan(flip(x3), flip(d3), -torch.exp(A_log.double()), flip(Bm), flip(Cm), D.double()))
+                zs = torch.nn.functional.silu(xz.view(B, L, 2 * ED)[..., ED:].double())
+                ref = y * zs + x3 * (1 - torch.sigmoid(zs)) if version == 1 else y * zs
+                got = ops.selective_scan(xc.cuda(), draw.cuda(), dtb.cuda(), A_log.cuda(), dbc.cuda(), rk, D.cuda(), xz.cuda(), B, L,
+                                         version=version, reverse=reverse)
+                err = (got.cpu().double().view(B, L, ED) - ref).abs().max().item()
+                assert err < 2e-4 * max(1.0, ref.abs().max().item()), (B, L, ED, N, reverse, version, err)

@@ -53,7 +53,7 @@ def alt_sd(g, rm, seed=5):
 def test_oracle_equals_reference_for_the_other_mamba_regmodels(golden):
     """'bimamba' (original gate), 'mamba' / 'mamba+' (one-directional ResidualBlock stacks)."""
     g = golden("g_reg.npz")
-    for rm in ("bimamba", "mamba", "mamba+", "moe_bimamba+", "sharedmoe_bimamba+", "lstm", "bilstm", "gru", "bigru", "cnngru", "cnnbigru"):
+    for rm in ("bimamba", "mamba", "mamba+", "moe_bimamba+", "sharedmoe_bimamba+", "lstm", "bilstm", "gru", "bigru", "cnngru", "cnnbigru", "moemamba"):
         sd = alt_sd(g, rm)
         ln_nd, inst = R.forward(sd, torch.from_numpy(g["alt_sem"]), torch.from_numpy(g["alt_emo"]), reg_model=rm)
         assert (ln_nd - torch.from_numpy(g[f"alt_{rm}_lnnd"])).abs().max() < 2e-5, rm

@@ -116,6 +116,68 @@ __global__ __launch_bounds__(CPB * N) void selective_scan_kernel(ScanParams p) {
     }
 }
 
+// The same scan for wider state spaces, N = 16 * NS states per channel ('moemamba' builds its blocks with d_state = d_hidden,
+// video_regression.py:143-147): a channel still owns 16 lanes, each lane carries NS states; operands are staged straight into
+// LDS (no register prefetch -- B and C rows alone are 2 * TCH * N floats per pass).
+template <int NS>
+__global__ __launch_bounds__(CPB * 16) void selective_scan_wide_kernel(ScanParams p) {
+    constexpr int N = 16 * NS, NT = CPB * 16, TW = 16;      // TW steps staged per pass (B and C rows: 2 * TW * N floats)
+    __shared__ float sx[TW][CPB], sd[TW][CPB], sz[TW][CPB], sy[TW][CPB], sB[TW][N], sC[TW][N];
+    const int tid = threadIdx.x, n = tid % 16, cl = tid / 16;
+    const int c0 = blockIdx.x * CPB, b = blockIdx.y;
+    const int ch = c0 + cl;
+    float A[NS], h[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        A[j] = ch < p.ED ? -__expf(p.A_log[(size_t)ch * N + j * 16 + n]) : 0.f;
+        h[j] = 0.f;
+    }
+    for (int s0 = 0; s0 < p.L; s0 += TW) {
+        const int steps = min(TW, p.L - s0);
+        for (int i = tid; i < TW * CPB; i += NT) {
+            const int s = i / CPB, cc = i % CPB;
+            const int t = p.reverse ? p.L - 1 - (s0 + s) : s0 + s;
+            const size_t row = (size_t)b * p.L + t;
+            const bool ok = s < steps && c0 + cc < p.ED;
+            sx[s][cc] = ok ? p.x[row * p.ldx + c0 + cc] : 0.f;
+            sd[s][cc] = ok ? softplus(p.draw[row * p.ldd + c0 + cc] + p.dt_bias[c0 + cc]) : 0.f;     // delta = 0: the step is a no-op
+            sz[s][cc] = ok ? silu(p.z[row * p.ldz + c0 + cc]) : 0.f;
+        }
+        for (int i = tid; i < TW * N; i += NT) {
+            const int s = i / N, nn = i % N;
+            const int t = p.reverse ? p.L - 1 - (s0 + s) : s0 + s;
+            const size_t row = (size_t)b * p.L + t;
+            sB[s][nn] = s < steps ? p.Bm[row * p.ldbc + nn] : 0.f;
+            sC[s][nn] = s < steps ? p.Cm[row * p.ldbc + nn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int s = 0; s < TW; ++s) {
+            const float delta = sd[s][cl], xv = sx[s][cl];
+            float part = 0.f;
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                const int nn = j * 16 + n;
+                h[j] = __expf(delta * A[j]) * h[j] + (delta * sB[s][nn]) * xv;
+                part += h[j] * sC[s][nn];
+            }
+            const float ys = group_sum<16>(part);
+            if (n == 0) sy[s][cl] = ys;
+        }
+        __syncthreads();
+        for (int i = tid; i < steps * CPB; i += NT) {
+            const int s = i / CPB, cc = i % CPB;
+            const int t = p.reverse ? p.L - 1 - (s0 + s) : s0 + s;
+            if (c0 + cc < p.ED) {
+                const float xv = sx[s][cc], zs = sz[s][cc];
+                const float yv = sy[s][cc] + p.D[c0 + cc] * xv;
+                p.y[((size_t)b * p.L + t) * p.ldy + c0 + cc] = p.version == 1 ? yv * zs + xv * (1.0f - 1.0f / (1.0f + __expf(-zs))) : yv * zs;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void concat2_kernel(const float* __restrict__ a, int da, const float* __restrict__ b, int db,
                                float* __restrict__ out, int rows, int ld_out) {
     const int row = blockIdx.x;
@@ -140,9 +202,17 @@ int32_t amt_launch_dwconv_silu(const float* x, int ldx, const float* w, const fl
 
 int32_t amt_launch_selective_scan(const ScanParams& p, hipStream_t stream) {
     AMT_CHECK_ARG(p.B > 0 && p.L > 0 && p.ED > 0, "selective_scan: bad shape B=%d L=%d ED=%d", p.B, p.L, p.ED);
-    AMT_CHECK_ARG(p.N == 16, "selective_scan: d_state=%d (built for the reference's default 16)", p.N);
+    AMT_CHECK_ARG(p.N == 16 || p.N == 32 || p.N == 64 || p.N == 128 || p.N == 256,
+                  "selective_scan: d_state=%d not in {16 (the reference's default), 32, 64, 128, 256}", p.N);
     AMT_CHECK_ARG(p.ldx >= p.ED && p.ldd >= p.ED && p.ldz >= p.ED && p.ldy >= p.ED && p.ldbc >= p.N, "selective_scan: bad leading dimension");
-    hipLaunchKernelGGL(selective_scan_kernel<16>, dim3(cdiv(p.ED, CPB), p.B), dim3(CPB * 16), 0, stream, p);
+    const dim3 grid(cdiv(p.ED, CPB), p.B), block(CPB * 16);
+    switch (p.N) {
+        case 16: hipLaunchKernelGGL(selective_scan_kernel<16>, grid, block, 0, stream, p); break;
+        case 32: hipLaunchKernelGGL(selective_scan_wide_kernel<2>, grid, block, 0, stream, p); break;
+        case 64: hipLaunchKernelGGL(selective_scan_wide_kernel<4>, grid, block, 0, stream, p); break;
+        case 128: hipLaunchKernelGGL(selective_scan_wide_kernel<8>, grid, block, 0, stream, p); break;
+        default: hipLaunchKernelGGL(selective_scan_wide_kernel<16>, grid, block, 0, stream, p); break;
+    }
     AMT_LAUNCH_CHECK();
     return 0;
 }

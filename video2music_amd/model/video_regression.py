@@ -71,10 +71,29 @@ class _RMSWeight(nn.Module):
 class _ResidualBlockParams(nn.Module):
     """ResidualBlock (mamba.py:131-147): keys mixer.*, norm.weight."""
 
-    def __init__(self, d_model):
+    def __init__(self, d_model, d_state=16, d_conv=4):
         super().__init__()
-        self.mixer = _MambaBlockParams(d_model)
+        self.mixer = _MambaBlockParams(d_model, d_state=d_state, d_conv=d_conv)
         self.norm = _RMSWeight(d_model)
+
+
+class _ResidualMoEParams(nn.Module):
+    """ResidualMoE (mamba.py:117-129): keys moe_layer.*, norm.weight."""
+
+    def __init__(self, moe, d_model):
+        super().__init__()
+        import copy
+        self.moe_layer = copy.deepcopy(moe)
+        self.norm = _RMSWeight(d_model)
+
+
+class _MoEMambaParams(nn.Module):
+    """MoEMamba (mamba.py:102-115): layers.{i}.0 = ResidualBlock, layers.{i}.1 = ResidualMoE."""
+
+    def __init__(self, moe, d_model, d_state, d_conv, n_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([nn.Sequential(_ResidualBlockParams(d_model, d_state, d_conv), _ResidualMoEParams(moe, d_model))
+                                     for _ in range(n_layers)])
 
 
 class _MambaStackParams(nn.Module):
@@ -109,14 +128,13 @@ class VideoRegression(nn.Module):
                  total_vf_dim=0, regModel="bilstm", scene_embed=False, chord_embed=False):
         super().__init__()
         if regModel not in ("bimamba+", "bimamba", "mamba", "mamba+", "moe_bimamba+", "sharedmoe_bimamba+", "lstm", "bilstm", "gru", "bigru",
-                            "cnngru", "cnnbigru"):
-            raise NotImplementedError("built: regModel 'bimamba+' (the callers' default), 'bimamba', 'mamba', 'mamba+', 'moe_bimamba+', "
-                                      "'sharedmoe_bimamba+', 'lstm', 'bilstm', 'gru', 'bigru', 'cnngru', 'cnnbigru'; 'minGRU' and 'moemamba' "
-                                      "(d_state = d_hidden) of video_regression.py:124-178 are not")
+                            "cnngru", "cnnbigru", "moemamba"):
+            raise NotImplementedError("built: every regModel of video_regression.py:124-178 ('bimamba+' is the callers' default); 'minGRU' has "
+                                      "no branch there either")
         self._version = 1 if regModel.endswith("+") else 0           # MambaConfig.use_version: 1 = the Mamba+ gate
         self._bidirectional = "bimamba" in regModel
         moe = None
-        if regModel in ("moe_bimamba+", "sharedmoe_bimamba+"):     # GLUExpert(d, 2d + 1), 6 experts, top-2 (:165-178)
+        if regModel in ("moe_bimamba+", "sharedmoe_bimamba+", "moemamba"):     # GLUExpert(d, 2d + 1), 6 experts, top-2 (:143-178)
             from .moe import GLUExpert, MoELayer, SharedMoELayer
             cls = MoELayer if regModel == "moe_bimamba+" else SharedMoELayer
             moe = cls(GLUExpert(d_model, d_model * 2 + 1), d_model, n_experts=6, n_experts_per_token=2, dropout=dropout)
@@ -141,6 +159,10 @@ class VideoRegression(nn.Module):
             else:
                 self.model = rnn
             self.__dict__["_rnn_mod"] = rnn          # an alias outside the module registry (no second set of keys)
+        elif regModel == "moemamba":                      # MoEMamba over blocks with d_state = d_hidden, d_conv = 8 (:143-150)
+            if d_hidden not in (16, 32, 64, 128, 256):
+                raise ValueError("'moemamba' uses d_state = d_hidden: the scan kernel takes 16, 32, 64, 128 or 256 states per channel")
+            self.model = _MoEMambaParams(moe, d_model, d_hidden, 8, n_layers)
         else:
             self.model = (_BiMambaEncoderParams(d_model, d_hidden, n_layers, self._version, moe) if self._bidirectional
                           else _MambaStackParams(d_model, n_layers))
@@ -162,7 +184,7 @@ class VideoRegression(nn.Module):
                 self._derived_sig = sig
             return
         blocks = ([m for l in self.model.layers for m in (l.mamba_forward, l.mamba_backward)] if self._bidirectional
-                  else [l.mixer for l in self.model.layers])
+                  else [(l[0] if isinstance(l, nn.Sequential) else l).mixer for l in self.model.layers])
         ws = [self.in_proj[0].weight] + [m.dt_proj.weight for m in blocks]
         xs = [m.x_proj.weight for m in blocks]
         sig = tuple((w.data_ptr(), w._version) for w in ws + xs)
@@ -254,8 +276,12 @@ class VideoRegression(nn.Module):
             return x.view(B, S, self._dirs * d)
         if not self._bidirectional:                     # Mamba.forward (mamba.py:73-78): x = mixer(norm(x)) + x per layer
             for i, lyr in enumerate(self.model.layers):
-                h = ops.rmsnorm(x, lyr.norm.weight.detach(), eps=lyr.norm.eps)
-                x = self._mamba(h, lyr.mixer, self._Wdt[i], self._Wx[i], B, S, x, False)
+                blk = lyr[0] if isinstance(lyr, nn.Sequential) else lyr
+                h = ops.rmsnorm(x, blk.norm.weight.detach(), eps=blk.norm.eps)
+                x = self._mamba(h, blk.mixer, self._Wdt[i], self._Wx[i], B, S, x, False)
+                if blk is not lyr:                      # ResidualMoE: moe_layer(norm(x)) + x (mamba.py:126-128)
+                    h = ops.rmsnorm(x, lyr[1].norm.weight.detach(), eps=lyr[1].norm.eps)
+                    x = ops.add(lyr[1].moe_layer(h.view(B, S, self.d_model)).reshape(B * S, self.d_model), x)
             return x.view(B, S, self.d_model)
         if self._version == 0:                          # BiMambaEncoderLayer.forward (bimamba.py:61-100)
             ln = lambda t, n, post=None: ops.layernorm_post(t, n.weight.detach(), n.bias.detach(), post=post, eps=n.eps)
