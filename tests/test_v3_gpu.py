@@ -66,3 +66,25 @@ def test_cli_runs_v3(tmp_path):
             "-target_seq_length_chord", "12", "--sampler", "argmax", "-music_gen_version", "3.1", "-output_dir", str(tmp_path)]
     a = G.main(argv).cpu()
     assert a.shape == (2, 12) and int(a[:, 1:].min()) >= 1
+
+
+@pytest.mark.parametrize("version,B,P", [("3.0", 3, 1), ("3.1", 4, 2), ("3.2", 2, 1)])
+def test_v3_generate_batch_equals_per_clip_generate(version, B, P):
+    """B clips re-forwarded together each step (each as a batch of one) give, clip by clip, the ids of `generate`."""
+    m = build(version)
+    T = 20
+    f = {k: v.cuda() for k, v in feats_t(synthetic.synthetic_features(B, seed=31)).items()}
+    rs = np.random.RandomState(B)
+    ids = torch.from_numpy(rs.randint(1, 157, size=(B, P)))
+    from video2music_amd.utilities.constants import chord_to_root_attr
+    ra = torch.tensor([[chord_to_root_attr(int(i)) for i in row] for row in ids])
+    pr = (ids, ra[:, :, 0], ra[:, :, 1])
+    args = (f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"])
+    with torch.no_grad():
+        for kw in (dict(beam=0, sampler="argmax"), dict(beam=1), dict(beam=0, sampler="argmax", temperature=0.8)):
+            got = m.generate_batch(*args, *pr, target_seq_length=T, **kw)
+            assert got.shape == (B, T)
+            for c in range(B):
+                one = m.generate(f["semantic"][c:c + 1], f["key"][c], f["scene_offset"][c:c + 1], f["motion"][c:c + 1], f["emotion"][c:c + 1],
+                                 pr[0][c], pr[1][c], pr[2][c], target_seq_length=T, **kw)
+                assert torch.equal(one[0], got[c]), (kw, c)

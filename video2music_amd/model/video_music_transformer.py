@@ -575,8 +575,14 @@ class VideoMusicTransformer_V2(nn.Module):
         if self._rope_cache is not None and clips:
             # independent clips, rows clip-major (B*L, E): each clip gets what the raw view does for a batch of one, i.e.
             # pair i of the E-wide vector at position l rotated by cache[l][i] -- one launch for all clips
-            q = ops.rope(q.view(B, Lq, 1, E), self._rope_cache).view(Lq * B, E)
-            k = ops.rope(k.view(B, Lk, 1, E), self._rope_cache).view(Lk * B, E)
+            if self._rope_cache.shape[1] * 2 == E:
+                q = ops.rope(q.view(B, Lq, 1, E), self._rope_cache).view(Lq * B, E)
+                k = ops.rope(k.view(B, Lk, 1, E), self._rope_cache).view(Lk * B, E)
+            else:       # a cache built for another width (V3 '3.0': dim = 2 d_model): the raw batch-of-one view, clip by clip
+                for t_, L_ in ((q, Lq), (k, Lk)):
+                    for c in range(B):
+                        rows = t_[c * L_:(c + 1) * L_].view(H, L_, 1, hd)
+                        ops.rope(rows, self._rope_cache, out=rows)
         elif self._rope_cache is not None:
             q = ops.rope(q.view(H, Lq, B, hd), self._rope_cache).view(Lq * B, E)       # raw (H, L, B, hd) view (:1041-1053)
             k = ops.rope(k.view(H, Lk, B, hd), self._rope_cache).view(Lk * B, E)
@@ -641,8 +647,10 @@ class VideoMusicTransformer_V2(nn.Module):
         t = self._ln(self._attention(t, memory, lyr.cross_attn, L, S, B, False, t), lyr.norm2)
         return self._ln(self._ff(t, lyr.ff, L, B), lyr.norm3, resid=t)
 
-    def _decode(self, x_root, x_attr, feature_key, memory, B, S):
-        """Chord stream + decoder stack + Wout (:437-452, :490-516) over a precomputed encoder memory."""
+    def _decode(self, x_root, x_attr, feature_key, memory, B, S, clips=False):
+        """Chord stream + decoder stack + Wout (:437-452, :490-516) over a precomputed encoder memory.  clips=True: the B
+        rows are independent clips (each computed as a batch of one), `memory` clip-major as `_encode_memory(clips=True)`
+        returns it."""
         from .. import ops
         dev = self.Wout.weight.device
         L, d = x_root.shape[1], self.d_model
@@ -652,11 +660,16 @@ class VideoMusicTransformer_V2(nn.Module):
         key = key.expand(B).contiguous() if key.numel() == 1 else key.contiguous()
         xf = ops.chord_embed(x_root.to(dev).long().contiguous(), x_attr.to(dev).long().contiguous(), key, self._PR, self._PA,
                              self._wkey, self.Linear_chord.bias.detach(), self._pe_chord)
-        t = xf.view(B, L, d).permute(1, 0, 2).contiguous().view(L * B, d)
-        for lyr in self.transformer.decoder.layers:
-            t = self._dec_layer(t, memory, lyr, L, S, B)
+        t = xf if clips else xf.view(B, L, d).permute(1, 0, 2).contiguous().view(L * B, d)
+        self._clip_rows = bool(clips)
+        try:
+            for lyr in self.transformer.decoder.layers:
+                t = self._dec_layer(t, memory, lyr, L, S, B)
+        finally:
+            self._clip_rows = False
         t = self._ln(t, self.transformer.decoder.norm)
-        t = t.view(L, B, d).permute(1, 0, 2).contiguous().view(B * L, d)
+        if not clips:
+            t = t.view(L, B, d).permute(1, 0, 2).contiguous().view(B * L, d)
         return ops.linear(t, self.Wout.weight.detach(), self.Wout.bias.detach()).view(B, L, CHORD_SIZE)
 
     # ---- KV-cached decode of one clip (B = 1) ----------------------------------------------------------------------
@@ -920,21 +933,27 @@ class VideoMusicTransformer_V2(nn.Module):
         # (6 ms for the softmax alone, found with cProfile), so the loop runs with one intra-op thread
         n_threads = torch.get_num_threads()
         torch.set_num_threads(1)
+        def next_logits(cur):                                           # logits of input position cur-1, (B, 159) on the host
+            if cur - 1 > 0:
+                feed(cur - 1)
+                graph.replay() if graph is not None else self._step_batch(st, keys, state)
+            return st["logits"].cpu() if cur >= P else None
+
         try:
-            return self._lockstep_loop(st, keys, state, feed, graph, gen, gen_root, gen_attr, ra_table, nb, T, P, beam, max_conseq_N,
+            return self._lockstep_loop(next_logits, gen, gen_root, gen_attr, ra_table, nb, T, P, beam, max_conseq_N,
                                        max_conseq_chord, temperature, sampler).to(dev)
         finally:
             torch.set_num_threads(n_threads)
 
-    def _lockstep_loop(self, st, keys, state, feed, graph, gen, gen_root, gen_attr, ra_table, nb, T, P, beam, max_conseq_N,
-                       max_conseq_chord, temperature, sampler):
+    def _lockstep_loop(self, next_logits, gen, gen_root, gen_attr, ra_table, nb, T, P, beam, max_conseq_N, max_conseq_chord,
+                       temperature, sampler):
+        """The per-position decision of `generate` (:547-600) for B clips at once; `next_logits(cur)` supplies the logits that
+        decide position cur (None inside the primer)."""
         for cur in range(1, T):
-            if cur - 1 > 0:                                             # logits of input position cur-1
-                feed(cur - 1)
-                graph.replay() if graph is not None else self._step_batch(st, keys, state)
-            if cur < P:
+            lg = next_logits(cur)
+            if lg is None:
                 continue
-            probs = torch.softmax(st["logits"].cpu() / temperature, dim=-1)[:, :CHORD_END]     # per row the arithmetic of `generate`
+            probs = torch.softmax(lg / temperature, dim=-1)[:, :CHORD_END]     # per row the arithmetic of `generate`
             if beam == 1:
                 tok = probs.argmax(-1)                                  # topk(., 1) per clip (:547-560); no root/attr feedback
                 gen[:, cur] = tok
@@ -1217,8 +1236,12 @@ class VideoMusicTransformer_V3(VideoMusicTransformer_V2):
         q = ops.linear(xq, a.q_proj.weight.detach())                                 # (Lq*B, 2E)
         k = ops.linear(xkv, a.k_proj.weight.detach())
         v = ops.linear(xkv, a.v_proj.weight.detach())                                # (Lk*B, E)
-        q = ops.rope(q.view(2 * H, Lq, B, hd), self._rope_cache).view(-1)            # raw (2H, L, B, hd) view (:779-785)
-        k = ops.rope(k.view(2 * H, Lk, B, hd), self._rope_cache).view(-1)
+        if getattr(self, "_clip_rows", False):        # independent clips, clip-major rows: per clip the batch-of-one rotation
+            q = ops.rope(q.view(B, Lq, 1, 2 * E), self._rope_cache).view(-1)
+            k = ops.rope(k.view(B, Lk, 1, 2 * E), self._rope_cache).view(-1)
+        else:
+            q = ops.rope(q.view(2 * H, Lq, B, hd), self._rope_cache).view(-1)        # raw (2H, L, B, hd) view (:779-785)
+            k = ops.rope(k.view(2 * H, Lk, B, hd), self._rope_cache).view(-1)
         # raw (B, L, 2H, hd) / (B, S, H, hd) views of the same memory (:787-789): flat row b*L + l, head j at column j*hd;
         # even heads at head stride 2 hd from offset 0, odd heads from offset hd; outputs (B, H, Lq, hd) contiguous
         o1 = torch.empty(B, H, Lq, hd, device=xq.device, dtype=torch.float32)
@@ -1248,16 +1271,46 @@ class VideoMusicTransformer_V3(VideoMusicTransformer_V2):
         return ops.add(t, self._ff(self._ln(t, lyr.norm3), lyr.ff, L, B))
 
     def generate_batch(self, feature_semantic_list, feature_key, feature_scene_offset, feature_motion, feature_emotion,
-                       primer, primer_root, primer_attr, **kw):
-        """B clips, one after the other (no cached lockstep step for V3, see the class docstring) -> (B, T)."""
-        kw.pop("use_graph", None)
+                       primer, primer_root, primer_attr, target_seq_length=300, beam=0, beam_chance=1.0, max_conseq_N=0,
+                       max_conseq_chord=2, temperature=1.0, sampler="categorical", use_graph=False):
+        """`generate` for B clips at once -> (B, T); row b equals `generate` on clip b alone.  V3 has no KV cache (see the
+        class docstring): every step re-runs the decoder over the prefix, here for all clips in one pass, each clip computed
+        as a batch of one (clip-major rows; the reference's raw views are then the B = 1 ones)."""
+        from ..utilities.constants import chord_to_root_attr
+        assert (not self.training), "Cannot generate while in training mode"
+        if beam not in (0, 1):
+            raise NotImplementedError("beam > 1 is not implemented (generate.py:347-349 asserts it out as well)")
+        dev = self.Wout.weight.device
+        T = int(target_seq_length)
+        if T > self._max_dec:
+            raise ValueError(f"chord sequence longer than the RoPE cache ({self._max_dec}), like in the reference")
         nb = feature_semantic_list.shape[0]
-        key = feature_key.reshape(-1)
-        key = key.expand(nb) if key.numel() == 1 else key
-        pr = [torch.as_tensor(q) for q in (primer, primer_root, primer_attr)]
-        rows = [self.generate(feature_semantic_list[c:c + 1], key[c], feature_scene_offset[c:c + 1], feature_motion[c:c + 1],
-                              feature_emotion[c:c + 1], *[(q if q.dim() == 1 else q[c]) for q in pr], **kw) for c in range(nb)]
-        return torch.cat(rows)
+        prim = [torch.as_tensor(q).long().cpu() for q in (primer, primer_root, primer_attr)]
+        prim = [q.unsqueeze(0).expand(nb, -1) if q.dim() == 1 else q for q in prim]
+        P = prim[0].shape[1]
+        gen = torch.full((nb, T), CHORD_PAD, dtype=torch.long)
+        gen_root = torch.full((nb, T), CHORD_ROOT_PAD, dtype=torch.long)
+        gen_attr = torch.full((nb, T), CHORD_ATTR_PAD, dtype=torch.long)
+        gen[:, :P], gen_root[:, :P], gen_attr[:, :P] = prim
+        if self.chord_embed:
+            gen_root[:, :P], gen_attr[:, :] = gen[:, :P], 0
+        key = feature_key.to(dtype=torch.float32).reshape(-1)
+        key = (key.expand(nb) if key.numel() == 1 else key).contiguous()
+        memory, _, S = self._encode_memory(feature_semantic_list, feature_scene_offset, feature_motion, feature_emotion, clips=True)
+        ra_table = torch.tensor([chord_to_root_attr(i) for i in range(CHORD_END)])
+
+        def next_logits(cur):
+            if cur < P:
+                return None
+            return self._decode(gen_root[:, :cur], gen_attr[:, :cur], key, memory, nb, S, clips=True)[:, cur - 1].cpu()
+
+        n_threads = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            return self._lockstep_loop(next_logits, gen, gen_root, gen_attr, ra_table, nb, T, P, beam, max_conseq_N, max_conseq_chord,
+                                       temperature, sampler).to(dev)
+        finally:
+            torch.set_num_threads(n_threads)
 
     def generate(self, *args, use_cache=False, use_graph=False, **kw):
         """The reference loop; every step re-runs the decoder on the whole prefix (see the class docstring)."""
