@@ -6,7 +6,10 @@ B=32 clips per GPU to T=1024 tokens (+ the all-gather of ids when N>1), inputs r
 Workload = BASELINE.json configs[1]: 6+6 layers, d_model=512, H=8, dff=1024, max_sequence_chord=1024,
 300-frame synthetic video features (F=1287), random-init procedural weights.
 
-    python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torchrun, one rank per GPU)
+    python bench.py [--gpus N --steps K --warmup W]
+N>1: one rank per GPU — either started by `python -m torch.distributed.run … bench.py --gpus N …` (the ranks read
+RANK / LOCAL_RANK / WORLD_SIZE), or, when no such environment is present, by this script itself: the parent starts the
+N ranks as child processes before anything touches a GPU and relays rank 0's line.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (attn_decode_kernel<64>, the
 K/V-streaming attention of the decode step): algorithmic fp32 K/V bytes / launch duration measured
@@ -16,18 +19,81 @@ with HIP events on the launch stream in an instrumented eager replay of the same
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+LIB = os.path.join(ROOT, "video2music_amd", "lib", "libamt_hip.so")
 
-if not os.path.exists(os.path.join(ROOT, "video2music_amd", "lib", "libamt_hip.so")) and int(os.environ.get("LOCAL_RANK", "0")) == 0:
-    import subprocess                                                        # the library is a build artefact: build it once if absent
-    subprocess.check_call([os.path.join(ROOT, "video2music_amd", "csrc", "build.sh")], stdout=sys.stderr)
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--seq", type=int, default=1024, help="target_seq_length = max_sequence_chord")
+    ap.add_argument("--layers", type=int, default=6)
+    ap.add_argument("--d_model", type=int, default=512)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_roofline", action="store_true")
+    return ap.parse_args()
+
+
+def ensure_library():
+    """The library is a build artefact: build it once if absent.  Ranks started together serialise on a
+    file lock, so nobody imports a half-written .so."""
+    if os.path.exists(LIB):
+        return
+    import fcntl
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    with open(os.path.join(os.path.dirname(LIB), ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if not os.path.exists(LIB):
+            subprocess.check_call([os.path.join(ROOT, "video2music_amd", "csrc", "build.sh")], stdout=sys.stderr)
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a torchrun environment: this parent — which has not imported torch
+    and never touches a GPU — starts the N ranks as children of `torch.distributed.run` (one process per GPU,
+    RCCL over xGMI), relays rank 0's JSON line and exits with the launcher's status.  No exec."""
+    import socket
+    ensure_library()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.lstrip().startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks finished without printing a result line\n")
+        rc = 1
+    sys.exit(rc)
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _a = parse_args()
+    if _a.gpus > 1:
+        launch_ranks(_a)                                                     # does not return
+
+ensure_library()
+import numpy as np                                                           # noqa: E402
+import torch                                                                 # noqa: E402
 from video2music_amd import dist as vdist                                   # noqa: E402
 from video2music_amd import synthetic                                        # noqa: E402
 from video2music_amd.model.video_music_transformer import VideoMusicTransformer   # noqa: E402
@@ -154,21 +220,34 @@ def whole_step(cfg, B, T, st, generate_ms):
             "note": "31 dependent launches per step: the step is bound by the launch chain, the streaming kernels by HBM"}
 
 
+def rehearsal(args, rank, world):
+    """AMT_BENCH_REHEARSAL=1 (tests/test_dist_gloo.py, no GPU): the launcher, the barriers, the one all_gather and the
+    MAX-over-ranks reduction with fabricated ids in place of the generate.  The line says so and carries no rate."""
+    B, T = args.batch, args.seq
+    lo = rank * B
+    toks = (torch.arange(lo, lo + B).view(-1, 1) * 10000 + torch.arange(T).view(1, -1)).long()
+    torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = vdist.all_gather_sequences(toks, world * B)
+    torch.distributed.barrier()
+    te = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    torch.distributed.all_reduce(te, op=torch.distributed.ReduceOp.MAX)
+    want = (torch.arange(world * B).view(-1, 1) * 10000 + torch.arange(T).view(1, -1)).long()
+    assert torch.equal(out, want)
+    if rank == 0:
+        print(json.dumps({"metric": "rehearsal_only_no_generate", "value": None, "n_gpus": world, "steps": args.steps,
+                          "data": "fabricated ids (AMT_BENCH_REHEARSAL=1)", "gathered": list(out.shape)}))
+    torch.distributed.destroy_process_group()
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
-    ap.add_argument("--seq", type=int, default=1024, help="target_seq_length = max_sequence_chord")
-    ap.add_argument("--layers", type=int, default=6)
-    ap.add_argument("--d_model", type=int, default=512)
-    ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--no_roofline", action="store_true")
-    args = ap.parse_args()
+    args = parse_args()
 
     rank, world, local = vdist.init()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("AMT_BENCH_REHEARSAL") == "1":
+        return rehearsal(args, rank, world)
     device = torch.device("cuda", local % torch.cuda.device_count())    # ranks share a GPU only in gloo rehearsals
     torch.cuda.set_device(device)
     B, T = args.batch, args.seq

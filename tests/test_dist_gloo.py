@@ -55,3 +55,26 @@ def test_two_rank_gather(tmp_path, n_clips):
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment: the parent starts the ranks itself and relays rank 0's
+    line (the first SCALE run died on an assert).  Rehearsal mode: gloo, fabricated ids, no GPU."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(AMT_BENCH_REHEARSAL="1", AMT_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--batch", "3", "--seq", "8"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["gathered"] == [6, 8]
+
+
+def test_bench_relays_a_failing_rank():
+    """A rank that raises (here: a negative shard size) must make the parent exit non-zero with no result line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(AMT_BENCH_REHEARSAL="1", AMT_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--batch", "-1", "--seq", "8"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0 and not p.stdout.decode().strip()

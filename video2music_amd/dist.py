@@ -1,7 +1,9 @@
 """Data-parallel sharding of video clips over the GPUs of one node (one process per GPU).
 
 The reference has no multi-device concept (``utilities/device.py:8-9`` hard-codes ``cuda:0``).
-Clips are independent units: each rank encodes and decodes its own shard with replicated weights
+Clips are independent units: each rank encodes and decodes its own CONTIGUOUS shard (SURVEY.md §8(e)
+suggested the interleave ``c mod world``; contiguous shards give the same balance and make the gathered
+matrix come out in clip order without a permutation) with replicated weights
 and the only exchange is ONE ``all_gather`` of the generated ``(B_local, T)`` int64 id matrices at
 the end (256 KiB per rank at B_local=32, T=1024 — latency-bound).
 ``torch.distributed`` backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the CPU tests.
@@ -43,24 +45,27 @@ def shard_bounds(n_clips, rank, world):
 
 def all_gather_sequences(tokens, n_clips=None):
     """Gathers the per-rank ``(B_local, T)`` id matrices into the global ``(n_clips, T)`` matrix on
-    every rank, in rank order (= clip order under ``shard_bounds``).  Ragged shards are padded to
-    the largest shard for the collective and trimmed afterwards."""
+    every rank, in rank order (= clip order under ``shard_bounds``) with ONE collective.
+
+    Shard sizes are never exchanged: with ``n_clips`` given they follow from ``shard_bounds`` on every
+    rank (ragged shards are padded to the largest one for the collective and trimmed afterwards);
+    without it every rank must hold the same number of clips (the bench's case)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return tokens
     if tokens.is_cuda and dist.get_backend() == "gloo":      # rehearsal path: gloo gathers host tensors
         return all_gather_sequences(tokens.cpu(), n_clips).to(tokens.device)
-    world = dist.get_world_size()
-    sizes = [torch.zeros(1, dtype=torch.long, device=tokens.device) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([tokens.shape[0]], dtype=torch.long, device=tokens.device))
-    sizes = [int(s) for s in sizes]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if n_clips is None:
+        sizes = [tokens.shape[0]] * world
+    else:
+        sizes = [hi - lo for lo, hi in (shard_bounds(n_clips, r, world) for r in range(world))]
+        assert tokens.shape[0] == sizes[rank], f"rank {rank} holds {tokens.shape[0]} clips, shard_bounds says {sizes[rank]}"
     mx = max(sizes)
     pad = tokens
     if tokens.shape[0] < mx:
         pad = torch.cat([tokens, tokens.new_zeros(mx - tokens.shape[0], tokens.shape[1])])
     out = torch.empty(world * mx, tokens.shape[1], dtype=tokens.dtype, device=tokens.device)
-    dist.all_gather_into_tensor(out, pad.contiguous()) if hasattr(dist, "all_gather_into_tensor") and tokens.is_cuda \
-        else dist.all_gather(list(out.view(world, mx, -1).unbind(0)), pad.contiguous())
-    parts = [out.view(world, mx, -1)[r, :sizes[r]] for r in range(world)]
-    res = torch.cat(parts)
-    assert n_clips is None or res.shape[0] == n_clips
-    return res
+    dist.all_gather_into_tensor(out, pad.contiguous())
+    if mx * world == sum(sizes):
+        return out
+    return torch.cat([out.view(world, mx, -1)[r, :sizes[r]] for r in range(world)])
