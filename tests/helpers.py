@@ -46,8 +46,8 @@ def amt_named_shapes(n_layers, num_heads, d_model, dim_feedforward, max_sequence
     return out
 
 
-def synthetic_sd(cfg, seed=0, dtype=torch.float32):
-    sd = synthetic.synthetic_state_dict(amt_named_shapes(**cfg), seed=seed)
+def synthetic_sd(cfg, seed=0, dtype=torch.float32, recipe="default"):
+    sd = synthetic.synthetic_state_dict(amt_named_shapes(**cfg), seed=seed, recipe=recipe)
     return {k: torch.from_numpy(v).to(dtype) for k, v in sd.items()}
 
 
@@ -102,6 +102,6 @@ def v2_named_shapes(n_layers, num_heads, d_model, dim_feedforward, total_vf_dim,
     return out + [("Wout.weight", (159, d)), ("Wout.bias", (159,))]
 
 
-def synthetic_sd_v2(cfg, seed=0):
-    sd = synthetic.synthetic_state_dict(v2_named_shapes(**cfg), seed=seed)
+def synthetic_sd_v2(cfg, seed=0, recipe="default"):
+    sd = synthetic.synthetic_state_dict(v2_named_shapes(**cfg), seed=seed, recipe=recipe)
     return {k: torch.from_numpy(v) for k, v in sd.items()}

@@ -84,7 +84,8 @@ def ref_rpr_attn(q, k, v, Er, H):
 
 
 @pytest.mark.parametrize("B,H,L,hd,er_len", [(1, 4, 1, 32, 300), (2, 4, 12, 32, 300), (3, 4, 64, 32, 300), (2, 8, 129, 64, 200),
-                                            (1, 8, 300, 64, 300), (2, 2, 257, 64, 1024), (1, 2, 70, 128, 128)])
+                                            (1, 8, 300, 64, 300), (2, 2, 257, 64, 1024), (1, 2, 70, 128, 128),
+                                            (1, 8, 1024, 64, 1024)])       # config 2's full length: L = er_len = 1024
 def test_rpr_attention_prefill(B, H, L, hd, er_len):
     rs = np.random.RandomState(L)
     E = H * hd

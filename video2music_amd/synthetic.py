@@ -57,13 +57,44 @@ def fill_tensor(name: str, shape, seed: int = 0) -> np.ndarray:
     return np.ascontiguousarray(t, dtype=np.float32)
 
 
-def synthetic_state_dict(named_shapes, seed: int = 0, skip=("pe",)):
-    """``{name: ndarray}`` for an iterable of ``(name, shape)``; buffers named ``*.pe`` are skipped."""
+# "feedback" recipe (round 2): the default recipe's greedy sequences are dominated by a constant component of the
+# decoder output (4-6 distinct ids in 64 tokens, mostly the repeat-suppression pattern a,a,b), which says little about
+# the root/attr feedback.  Stronger chord embeddings and weaker decoder sub-layers (the residual stream keeps the
+# token; the video memory's constant pull through the cross-attention is turned down) give >= 20 distinct ids in 64
+# tokens with top-1/top-2 margins >= 1e-2 at config 1 and config 2 (found by a random search over these five factors
+# with the CPU oracle, then confirmed on the reference: oracle/make_goldens_cfg2.py prints both statistics).
+FEEDBACK_SCALES = {"embedding": 8.0, "wout": 4.0, "self_attn": 0.5, "cross_attn": 0.1, "ffn": 0.5}
+
+
+def _feedback_scale(name: str) -> float:
+    leaf = name.split(".")[-1]
+    if name in ("embedding_root.weight", "embedding_attr.weight"):
+        return FEEDBACK_SCALES["embedding"]
+    if name == "Wout.weight":
+        return FEEDBACK_SCALES["wout"]
+    if name.startswith("transformer.decoder.layers") and leaf.endswith("weight") and "norm" not in name:
+        if ".self_attn." in name:
+            return FEEDBACK_SCALES["self_attn"]
+        if ".multihead_attn." in name or ".cross_attn." in name:
+            return FEEDBACK_SCALES["cross_attn"]
+        return FEEDBACK_SCALES["ffn"]
+    return 1.0
+
+
+def synthetic_state_dict(named_shapes, seed: int = 0, skip=("pe",), recipe: str = "default"):
+    """``{name: ndarray}`` for an iterable of ``(name, shape)``; buffers named ``*.pe`` are skipped.
+    ``recipe="feedback"`` rescales a few tensors of the default fill (see ``FEEDBACK_SCALES``)."""
+    assert recipe in ("default", "feedback")
     out = {}
     for name, shape in named_shapes:
         if name.split(".")[-1] in skip:
             continue
-        out[name] = fill_tensor(name, shape, seed)
+        t = fill_tensor(name, shape, seed)
+        if recipe == "feedback":
+            sc = _feedback_scale(name)
+            if sc != 1.0:
+                t = np.ascontiguousarray(t * np.float32(sc), dtype=np.float32)
+        out[name] = t
     return out
 
 
