@@ -172,3 +172,16 @@ def test_user_primer_chords_follow_the_reference_rules():
     assert rows[0] == (1, 1, 0) and rows[1] == (122, 10, 5)                   # plain roots carry attr 0 in a primer (:315-318)
     a = parse_generate_args(["--primer", "C Am"])[0]
     assert a.primer == "C Am" and a.num_prime_chord == 30 and not a.primer_from_dataset
+
+
+def test_moe_schedulers_follow_the_reference_or_refuse():
+    """moe.py:160-179: MoELayer's schedulers act in training only (kept, no effect here); SharedMoELayer's temperature
+    scheduler divides the routing weights in eval too (:238-240,288) — refused rather than silently ignored."""
+    from video2music_amd.model.moe import GLUExpert, MoELayer, SharedMoELayer
+    sched = object()
+    a = MoELayer(GLUExpert(16, 32), 16, topk_scheduler=sched, temperature_scheduler=sched)
+    assert a.topk_scheduler is sched and a.temperature_scheduler is sched
+    b = SharedMoELayer(GLUExpert(16, 32), 16, topk_scheduler=sched)
+    assert b.topk_scheduler is sched
+    with pytest.raises(NotImplementedError, match="temperature"):
+        SharedMoELayer(GLUExpert(16, 32), 16, temperature_scheduler=sched)

@@ -249,12 +249,22 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
 
 template <int KCH, bool FULL, int PRO>
 int32_t launch_one(const DecodeGemmParams& p, size_t lds, hipStream_t stream) {
-    static bool attr_set = false;        // > 64 KiB of dynamic LDS needs the opt-in (gfx950: 160 KiB per CU)
-    if (!attr_set) {
-        AMT_HIP(hipFuncSetAttribute((const void*)decode_gemm_kernel<KCH, FULL, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    // > 64 KiB of dynamic LDS needs the opt-in (gfx950: 160 KiB per CU).  The attribute belongs to the (function, device)
+    // pair, so the flag is kept per device ordinal and per instantiation, under a lock (host threads may launch concurrently)
+    static bool attr_set[64] = {false};
+    static std::mutex mu;
+    int dev = 0;
+    AMT_HIP(hipGetDevice(&dev));
+    AMT_CHECK_ARG(dev >= 0 && dev < 64, "decode_gemm: device ordinal %d out of range", dev);
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!attr_set[dev]) {
+            AMT_HIP(hipFuncSetAttribute((const void*)decode_gemm_kernel<KCH, FULL, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set[dev] = true;
+        }
     }
     hipLaunchKernelGGL((decode_gemm_kernel<KCH, FULL, PRO>), dim3(cdiv(p.N, 16), cdiv(p.B, MT)), dim3(NW * 64), lds, stream, p);
+    AMT_LAUNCH_CHECK();
     return 0;
 }
 

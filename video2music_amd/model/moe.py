@@ -232,6 +232,12 @@ class MoELayer(_MoEBase):
         self.dropout = nn.Dropout(dropout)
         self.experts = nn.ModuleList([copy.deepcopy(expert) for _ in range(n_experts)])    # _get_clones, :157
         self.gate = nn.Linear(d_model, n_experts)
+        # moe.py:167-179: both schedulers act under `self.training` only; this build is inference-only (forward refuses
+        # training mode), so they are kept as attributes like the reference does and have no effect
+        if topk_scheduler is not None:
+            self.topk_scheduler = topk_scheduler
+        if temperature_scheduler is not None:
+            self.temperature_scheduler = temperature_scheduler
 
     def forward(self, x):
         return self._run(x)
@@ -245,6 +251,13 @@ class SharedMoELayer(_MoEBase):
         super().__init__()
         if use_KAN:
             raise NotImplementedError("KAN gates need efficient_kan (absent); outside the hot path")
+        if temperature_scheduler is not None:
+            # moe.py:238-240,288: this class steps the temperature and divides the routing weights by it in eval mode too;
+            # the fused router has no temperature input, and silently ignoring it would route differently from the reference
+            raise NotImplementedError("SharedMoELayer(temperature_scheduler=...) changes eval-time routing weights "
+                                      "(reference moe.py:238-240,288); not built — no reference model passes one")
+        if topk_scheduler is not None:          # training-only (:232-236)
+            self.topk_scheduler = topk_scheduler
         self.n_experts, self.n_experts_per_token, self.d_model = n_experts, n_experts_per_token, d_model
         self.dropout = nn.Dropout(dropout)
         self.experts = nn.ModuleList([copy.deepcopy(expert) for _ in range(n_experts)])    # :209
