@@ -59,9 +59,19 @@ __device__ __forceinline__ float sq4(const float4 a, float m) {
 // rows first and no branch in between, the prologue waits for the (L2-resident) rows alone while the weight tiles
 // (Infinity Cache / HBM) are still in flight.  A conditional load anywhere in that sequence degrades every later
 // wait to vmcnt(0), i.e. serialises the prologue behind the weights.
+#ifdef AMT_STAMPS
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); st_[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 template <int KCH, bool FULL, int PRO>
 __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef AMT_STAMPS
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    STAMP(0);
     const int K = p.K, LD = K + XPAD;
     float* xs = smem;                               // [16][LD]
     float* red = smem;                              // [16 waves][4 r][64 lanes], reuses xs after the MFMA phase
@@ -116,6 +126,7 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
         wt[i] = ld4(p.ldw ? wrow + (size_t)kt * 16 : wbase + ((size_t)kt * 64 + lane) * 4);
     }
     __builtin_amdgcn_sched_barrier(0);              // the scheduler must not sink any of these loads below this point
+    STAMP(1);
     const int el = tid & 63, er = (tid >> 6) & 3;
     const int row = m0 + 4 * (el >> 4) + er, n = nt * 16 + (el & 15);
     const bool live = tid < 256 && row < p.B && n < p.N;
@@ -181,7 +192,9 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
         const int i = (c * 64 + lane) * 4;
         if (FULL || i < K) st4(xs + wave * LD + i, v[c]);    // (rows >= B hold a copy of row B-1; their outputs are never stored)
     }
+    STAMP(2);
     __syncthreads();
+    STAMP(3);
 
     // ---- 4. epilogue operands: issued behind the prologue so that no register of the prologue's arithmetic sits
     // next to a pending load (packed VALU ops read register pairs).  Absent operands read a zero word instead of
@@ -217,11 +230,16 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
         }
     }
     // ---- cross-wave reduction in fixed order (the partial tiles reuse the xs region) ----
+#ifdef AMT_STAMPS
+    if (acc[0] == 1.2345e-30f) st_[7] = 1;          // the stamp must follow the MFMA results, not just their issue
+#endif
+    STAMP(4);
     __syncthreads();
     float* rw = red + wave * 256;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) rw[rr * 64 + lane] = acc[rr];
     __syncthreads();
+    STAMP(5);
     if (live) {
         float val = 0.f;
 #pragma unroll
@@ -245,6 +263,13 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
             }
         }
     }
+#ifdef AMT_STAMPS
+    STAMP(6);
+    if (p.stamps && tid == 0) {
+        unsigned long long* o = p.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        for (int i = 0; i < 8; ++i) o[i] = st_[i];
+    }
+#endif
 }
 
 template <int KCH, bool FULL, int PRO>

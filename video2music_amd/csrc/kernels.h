@@ -124,6 +124,9 @@ struct DecodeGemmParams {
     const int* sel; size_t sel_w_stride; int sel_b_stride;
     int ldw;                    // > 0: Wp is NOT packed but a plain nn.Linear weight [N][ldw] (small-M products of the dense paths)
     const float* zero;          // set by the launcher: zero words in global memory
+    // diagnostic builds only (-DAMT_STAMPS, tools/ubench_chain.cpp): [workgroup][8] s_memrealtime stamps (100 MHz) of the
+    // kernel's phases; null and unused in the library build
+    unsigned long long* stamps;
 };
 int32_t amt_launch_decode_gemm(const DecodeGemmParams& p, hipStream_t stream);
 // allocates the per-device zero words (hipMalloc): call once outside any stream capture
