@@ -11,9 +11,11 @@ N>1: one rank per GPU — either started by `python -m torch.distributed.run …
 RANK / LOCAL_RANK / WORLD_SIZE), or, when no such environment is present, by this script itself: the parent starts the
 N ranks as child processes before anything touches a GPU and relays rank 0's line.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (attn_decode_kernel<64>, the
-K/V-streaming attention of the decode step): algorithmic fp32 K/V bytes / launch duration measured
-with HIP events on the launch stream in an instrumented eager replay of the same generate.
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (attn_decode_kernel<64>, the K/V-streaming
+self-attention of the decode step): algorithmic fp32 K/V bytes / the kernel's launch duration inside the captured step
+graph, measured with HIP events on the launch stream; it also carries the cross-attention, the skinny GEMMs, the
+step-level figure (`whole_step`, the honest headline of the decode path) and `prefill` = the cross-attention
+QK^T/PV kernel of the teacher-forced forward against the fp32 MFMA peak (the north star's named target).
 `cpu_baseline` times the CPU oracle (port of the reference's no-KV-cache loop) on the host cores.
 """
 import argparse
@@ -100,6 +102,7 @@ from video2music_amd.model.video_music_transformer import VideoMusicTransformer 
 from video2music_amd.utilities import constants as C                          # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32-in / f32-acc matrix peak (same file)
 
 
 def make_model(cfg, device, seed=0):
@@ -112,45 +115,110 @@ def make_model(cfg, device, seed=0):
 
 def cpu_baseline(cfg, sd, T, budget_s=25.0):
     """Per-length cost of one step of the reference loop (full re-forward incl. encoder, no KV
-    cache, B=1: model/video_music_transformer.py:1069-1071) integrated over the T-1 steps of a clip."""
+    cache, B=1: model/video_music_transformer.py:1069-1071) integrated over the T-1 steps of a clip.
+    Timed with all of this GPU's host-core share (16 threads) and, coarser, with 8 threads (SURVEY.md §8(d):
+    comparable with the survey container's figures)."""
     from oracle import amt_oracle as O
     prev_threads = torch.get_num_threads()
-    # the GPU box gives one GPU a 16-CPU share; more intra-op threads only add overhead at these sizes
-    threads = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
     feats = synthetic.synthetic_features(1, seed=99)
     f = {k: torch.from_numpy(v) for k, v in feats.items()}
+
+    def per_clip_seconds(threads, lengths, budget):
+        torch.set_num_threads(threads)
+        rs = np.random.RandomState(0)
+        cost = []
+        t_start = time.time()
+        with torch.no_grad():
+            for L in lengths:
+                root = torch.from_numpy(rs.randint(1, 13, size=(1, L)))
+                attr = torch.from_numpy(rs.randint(1, 14, size=(1, L)))
+                reps, best = 0, float("inf")
+                while reps < 2 or (reps < 3 and time.time() - t_start < budget * 0.6):
+                    t0 = time.perf_counter()
+                    O.forward(sd, cfg["num_heads"], root, attr, f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"])
+                    best = min(best, time.perf_counter() - t0)
+                    reps += 1
+                cost.append(best)
+        return float(np.trapezoid(np.interp(np.arange(1, T), lengths, cost)))
+
+    # the GPU box gives one GPU a 16-CPU share; more intra-op threads only add overhead at these sizes
+    threads = min(16, os.cpu_count() or 1)
     lengths = sorted({1, T // 16, T // 8, T // 4, (3 * T) // 8, T // 2, (5 * T) // 8, (3 * T) // 4, (7 * T) // 8, T - 1})
-    rs = np.random.RandomState(0)
-    cost = []
-    t_start = time.time()
-    with torch.no_grad():
-        for L in lengths:
-            root = torch.from_numpy(rs.randint(1, 13, size=(1, L)))
-            attr = torch.from_numpy(rs.randint(1, 14, size=(1, L)))
-            reps, best = 0, float("inf")
-            while reps < 2 or (reps < 3 and time.time() - t_start < budget_s * 0.6):
-                t0 = time.perf_counter()
-                O.forward(sd, cfg["num_heads"], root, attr, f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"])
-                best = min(best, time.perf_counter() - t0)
-                reps += 1
-            cost.append(best)
-    per_clip = float(np.trapezoid(np.interp(np.arange(1, T), lengths, cost)))
+    per_clip = per_clip_seconds(threads, lengths, budget_s)
+    coarse = sorted({1, T // 4, T // 2, (3 * T) // 4, T - 1})
+    per_clip8 = per_clip_seconds(min(8, threads), coarse, budget_s * 0.5)
     torch.set_num_threads(prev_threads)
     return {"value": round((T - 1) / per_clip, 3), "unit": "chord-tokens/s", "cores": threads, "kind": "port",
             "sample": f"oracle forward (no KV cache, encoder re-run, B=1) timed at L={lengths} (best of 2-3), "
                       f"integrated over the {T - 1} steps of one clip = {per_clip:.1f} s/clip; clips run sequentially",
+            "value_8_threads": round((T - 1) / per_clip8, 3),
+            "sample_8_threads": f"same, {min(8, threads)} threads, L={coarse} (best of 2): {per_clip8:.1f} s/clip",
             "host_cpus": os.cpu_count()}
 
 
-def roofline(model, f, prim, B, T, cfg):
-    """Roofline of the dominant decode kernel (the K/V-streaming relative-position self-attention).
+def _sha256(path):
+    import hashlib
+    with open(path, "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()
 
-    Primary measurement: one full generate is replayed eagerly with a HIP event pair recorded on the
-    launch stream around EVERY kernel launch (amt_generate_profile); the mean pair time minus the
-    mean time of an empty pair is the kernel's average launch duration.  achieved = algorithmic fp32
-    K/V bytes per launch / that duration.  `in_situ` adds the cost of the kernel inside the captured
-    step graph: (generate ms - generate ms with the kernel left out of the graph) / launches.
+
+def pmc_traffic(kind, algorithmic_bytes_per_launch):
+    """HBM bytes per launch of the decode attention from the committed PMC pass (FETCH_SIZE doubled per the gfx950 correction +
+    WRITE_SIZE, collected by tools/pmc_attn.py under rocprofv3 --pmc in separate passes) scaled to this run's algorithmic bytes.
+    Counters cannot be read from inside bench.py, so the figure is only reported while the kernel source is byte-identical to
+    the one the pass was collected on (sha256 recorded in the profile); otherwise null."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_attn_traffic.json")
+    src = os.path.join(ROOT, "video2music_amd", "csrc", "attn_decode.hip")
+    if not (os.path.exists(path) and os.path.exists(src)):
+        return None, "no committed PMC pass"
+    prof = json.load(open(path))
+    if prof.get("kernel_source_sha256") != _sha256(src):
+        return None, "profiles/r02_pmc_attn_traffic.json was collected on another version of attn_decode.hip"
+    return round(prof[kind]["traffic_over_algorithmic"] * algorithmic_bytes_per_launch), \
+        "profiles/r02_pmc_attn_traffic.json (committed rocprofv3 --pmc pass on this kernel source, scaled to this run's bytes)"
+
+
+def prefill_roofline(B, L, S, H, hd, device, reps=20):
+    """North-star MFMA figure: the cross-attention prefill kernel (attn_prefill_kernel<64,false>, QK^T + PV of the teacher-forced
+    forward, model/rpr.py:62-63) at config 2's shape, timed with HIP events on the launch stream: 4*B*L*S*d flop per launch
+    against the dense fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md)."""
+    from video2music_amd import _lib
+    d = H * hd
+    q = torch.randn(B, L, d, device=device) * 0.1
+    k = torch.randn(B, S, d, device=device)
+    v = torch.randn(B, S, d, device=device)
+    o = torch.empty(B, L, d, device=device)
+
+    def run():
+        _lib.call("amt_cross_attn_fwd", _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), B, H, L, S, hd, 0, _lib.stream_ptr())
+
+    for _ in range(3):
+        run()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        run()
+    b.record()
+    torch.cuda.synchronize()
+    us = 1e3 * a.elapsed_time(b) / reps
+    flop = 4.0 * B * L * S * d
+    return {"bound": "mfma", "kernel": "attn_prefill_kernel<64, false> (cross-attention QK^T + PV of the teacher-forced forward)",
+            "shape": f"B={B} L={L} S={S} H={H} hd={hd} (grid (2048,8,32)/256... one launch per decoder layer of the config-2 forward)",
+            "flop_per_launch": flop, "avg_launch_us": round(us, 2), "achieved": round(flop / us / 1e6, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(flop / us / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "dtype": "f32 in / f32 accumulate (v_mfma_f32_32x32x2_f32)",
+            "measured": f"HIP events on the launch stream around {reps} back-to-back launches of the operator entry point (same kernel, "
+                        "same grid as the forward's)"}
+
+
+def roofline(model, f, prim, B, T, cfg):
+    """Roofline of the decode step's kernels.
+
+    Dominant kernel = the K/V-streaming relative-position self-attention.  Two measurements of its launch duration:
+      * in the captured step graph (what the kernel costs the step): (generate ms - generate ms with the kernel left out of the
+        graph) / launches, median of 3 interleaved rounds, HIP events on the launch stream around whole generates.  `achieved`
+        and `frac` are computed from THIS figure: it includes the kernel boundary and is the conservative one;
+      * HIP event pair around every launch of an eager replay of the same generate (amt_generate_profile), reported as
+        `event_pair` both raw and minus the cost of an empty pair.  rocprofv3's kernel-trace average (profiles/) lies between the two.
     """
     with torch.no_grad():
         _, st = model.generate_profile(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], *prim,
@@ -172,44 +240,59 @@ def roofline(model, f, prim, B, T, cfg):
         model._debug_set_skip(0)
     empty_us = 1e3 * st["empty_event_pair"]["ms"] / st["empty_event_pair"]["launches"]
 
-    def avg_us(k):
-        return max(1e3 * st[k]["ms"] / st[k]["launches"] - empty_us, 1e-3)
+    def raw_us(k):
+        return 1e3 * st[k]["ms"] / st[k]["launches"]
 
-    def gbs(k):
-        return st[k]["bytes"] / st[k]["launches"] / avg_us(k) / 1e3
+    def ev(k, nbytes=None):
+        raw, cor = raw_us(k), max(raw_us(k) - empty_us, 1e-3)
+        o = {"avg_launch_us_raw": round(raw, 3), "avg_launch_us_minus_empty_pair": round(cor, 3)}
+        if nbytes:
+            o["GBps_minus_empty_pair"] = round(nbytes / cor / 1e3, 1)
+        return o
 
     full, no_self, no_cross = (float(np.median([r[i] for r in rounds])) for i in range(3))
     n = st["self_attn_decode"]["launches"]
-    # HBM traffic per launch from the committed PMC pass (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE),
-    # expressed as a ratio to the algorithmic bytes of the same launches; counters cannot be read from inside bench.py
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_attn_traffic.json")
-    if os.path.exists(pmc) and cfg["d_model"] == 512:
-        traffic = round(json.load(open(pmc))["self_attn"]["traffic_over_algorithmic"] * st["self_attn_decode"]["bytes"] / n)
+    self_bytes = st["self_attn_decode"]["bytes"] / n
+    cross_bytes = st["cross_attn_decode"]["bytes"] / n
+    self_us, cross_us = 1e3 * (full - no_self) / n, 1e3 * (full - no_cross) / n
+    steps = T - 1
+    step_us = 1e3 * full / steps
+    d, dff, nl = cfg["d_model"], cfg["dim_feedforward"], cfg["n_layers"]
+    # the skinny GEMMs: packed weights read per launch (folded chain: [Wo | W'.Wo, W'] etc.), 3 launches per layer
+    gemm_bytes = (nl * 3 * d * d + nl * (d * d + 2 * d * dff) + nl * d * dff + (nl - 1) * 3 * d * (dff + d) + 160 * (dff + d)) * 4 / (3 * nl)
+    n_gemm = st["decode_gemm"]["launches"] / steps
+    sample_us = max(raw_us("sample") - empty_us, 0.0)
+    gemm_in_chain_us = (step_us - nl * (self_us + cross_us) - sample_us) / max(n_gemm, 1)
+    traffic, traffic_src = pmc_traffic("self_attn", self_bytes)
     return {
         "bound": "hbm", "kernel": "attn_decode_kernel<64, true, true, {0,2}> (relative-position self-attention, decode step; FOLD 2 in layers 1-5)",
-        "achieved": round(gbs("self_attn_decode"), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(gbs("self_attn_decode") / HBM_PEAK_GBS, 4), "traffic": traffic,
-        "launches": n, "avg_launch_us": round(avg_us("self_attn_decode"), 3),
-        "algorithmic_bytes_per_launch": round(st["self_attn_decode"]["bytes"] / n),
-        "measured": "HIP event pair on the launch stream around every launch of an eager replay of one full generate, "
-                    f"minus the empty-pair cost ({empty_us:.2f} us)",
-        "second_kernel": {"kernel": "attn_decode_kernel<64, false, true, 1> (cross-attention over video K/V, decode step)",
-                          "achieved": round(gbs("cross_attn_decode"), 1), "frac": round(gbs("cross_attn_decode") / HBM_PEAK_GBS, 4),
-                          "avg_launch_us": round(avg_us("cross_attn_decode"), 3),
-                          "algorithmic_bytes_per_launch": round(st["cross_attn_decode"]["bytes"] / n)},
-        "other_kernels_avg_us": {k: round(avg_us(k), 3) for k in ("decode_gemm", "sample")},
+        "achieved": round(self_bytes / self_us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(self_bytes / self_us / 1e3 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+        "launches": n, "avg_launch_us": round(self_us, 3), "algorithmic_bytes_per_launch": round(self_bytes),
+        "measured": "in the captured step graph: (generate ms - generate ms with the kernel left out of the graph) / launches, HIP events "
+                    "on the launch stream, median of 3 interleaved rounds; includes the kernel boundary",
+        "generate_ms": {"full": round(full, 2), "without_self_attn": round(no_self, 2), "without_cross_attn": round(no_cross, 2)},
+        "event_pair": dict(ev("self_attn_decode", self_bytes), empty_pair_us=round(empty_us, 2),
+                           method="HIP event pair on the launch stream around every launch of an eager replay of one full generate"),
+        "cross_attn": {"kernel": "attn_decode_kernel<64, false, true, 1> (cross-attention over video K/V, decode step)",
+                       "algorithmic_bytes_per_launch": round(cross_bytes), "avg_launch_us": round(cross_us, 3),
+                       "achieved": round(cross_bytes / cross_us / 1e3, 1), "frac": round(cross_bytes / cross_us / 1e3 / HBM_PEAK_GBS, 4),
+                       "traffic": pmc_traffic("cross_attn", cross_bytes)[0], "event_pair": ev("cross_attn_decode", cross_bytes)},
+        "decode_gemm": {"kernel": "decode_gemm_kernel<4,true,0> (G1, G2) and <6,true,2> (G3): weight-streaming skinny GEMMs, 18 launches per step",
+                        "packed_weight_bytes_per_launch": round(gemm_bytes), "avg_launch_us": round(gemm_in_chain_us, 3),
+                        "achieved": round(gemm_bytes / gemm_in_chain_us / 1e3, 1), "frac": round(gemm_bytes / gemm_in_chain_us / 1e3 / HBM_PEAK_GBS, 4),
+                        "measured": "in the chain: (step us - attention launches - sampling head) / GEMM launches; latency-bound "
+                                    "(profiles/r02_skinny_gemm_timeline_before.txt, r02_pmc_decode_step_SQ.json: 86 % of wave cycles waiting)",
+                        "event_pair": ev("decode_gemm", gemm_bytes)},
+        "sample_event_pair": ev("sample"),
         "whole_step": whole_step(cfg, B, T, st, full),
-        "in_situ": {"method": "generate ms minus generate ms with the kernel left out of the step graph, per launch; "
-                              "median of 3 interleaved rounds",
-                    "generate_ms": {"full": round(full, 2), "without_self_attn": round(no_self, 2), "without_cross_attn": round(no_cross, 2)},
-                    "self_attn_us": round(1e3 * (full - no_self) / n, 3), "cross_attn_us": round(1e3 * (full - no_cross) / n, 3)},
+        "prefill": prefill_roofline(B, T, 300, cfg["num_heads"], d // cfg["num_heads"], f["semantic"].device),
     }
 
 
 def whole_step(cfg, B, T, st, generate_ms):
-    """SURVEY.md §8(d) step-level figure: algorithmic bytes of one average decode step (decoder weights read once, the
-    clips' cross-attention K/V, the self-attention K/V at the mean length) over the measured step time."""
+    """SURVEY.md §8(d) step-level figure — the honest headline of the decode path: algorithmic bytes of one average decode step
+    (decoder weights read once, the clips' cross-attention K/V, the self-attention K/V at the mean length) over the measured step time."""
     d, dff, nl, S = cfg["d_model"], cfg["dim_feedforward"], cfg["n_layers"], 300
     steps = T - 1
     weights = nl * (8 * d * d + 2 * d * dff) * 4 + (159 * d + (d + 1) * d) * 4
@@ -217,7 +300,9 @@ def whole_step(cfg, B, T, st, generate_ms):
     us = 1e3 * generate_ms / steps
     return {"algorithmic_bytes_per_step": round(weights + kv), "us_per_step_incl_encode": round(us, 2),
             "achieved": round((weights + kv) / us / 1e3, 1), "unit": "GB/s", "frac": round((weights + kv) / us / 1e3 / HBM_PEAK_GBS, 4),
-            "note": "31 dependent launches per step: the step is bound by the launch chain, the streaming kernels by HBM"}
+            "frac_of_achievable_6300": round((weights + kv) / us / 1e3 / 6300.0, 4),
+            "note": "31 dependent launches per step (~1.2 us boundary each, profiles/r02_skinny_gemm_timeline_before.txt): the step is bound "
+                    "by the launch chain, the streaming kernels by HBM"}
 
 
 def rehearsal(args, rank, world):
