@@ -36,8 +36,14 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int qblk = gridDim.x - 1 - blockIdx.x;        // heavy (late) causal blocks first
-    const int h = blockIdx.y, b = blockIdx.z;
+    // 1-D grid, query block slowest: all (clip, head) pairs of the heaviest (last) causal query block are dispatched first, then
+    // the next lighter one, ... (longest-processing-time order: the tail of the launch is made of 4-tile blocks instead of
+    // 32-tile ones), and the linear id of a (clip, head) is the same in every group, so under round-robin block->XCD
+    // placement all query blocks of a (clip, head) read its K/V through the same XCD's L2
+    const int n_bh = p.H * p.B, n_qb = (p.Lq + QB - 1) / QB;
+    const int qblk = n_qb - 1 - (int)(blockIdx.x / n_bh);
+    const int bh = blockIdx.x % n_bh;
+    const int h = bh % p.H, b = bh / p.H;
     const int hk = h / p.kv_group;
     const int I0 = qblk * QB, i0 = I0 + wave * 32, iq = i0 + li;
     float* scr = scr_all + wave * SCR;
@@ -92,6 +98,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
         }
     };
 
+    float4 er_next[NS];                    // Er rows of the chunk the next tile will need (relative positions only)
+    bool er_primed = false;
+    // (double-buffering the tiles in LDS for one barrier per tile was measured: 587 vs 584 us at config 2 — no gain, more LDS)
     gload(0);
     for (int kt = 0; kt < n_tiles; ++kt) {
         const int j0 = kt * KT;
@@ -118,15 +127,19 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
         //      aligned chunks k-1 and k of 32 distances each; chunk c holds R^T[m][query] = Er[er_len-1-(32c+m)] . q.
         //      Tiles are visited with k descending, so chunk k was produced by the previous tile (as its k-1) and
         //      only chunk k-1 is new: one extra MFMA tile per key tile, kept in a 2-slot per-wave LDS ring. ----
-        if (RPR) {
+        if constexpr (RPR) {
             const int k = (i0 - j0) / 32;
-            auto chunk = [&](int c) {
+            // The Er rows of a chunk come straight from L2 (the table is shared by every clip and head).  The rows of the NEXT
+            // tile's chunk (k-2) are requested as soon as this tile's fragments are in the matrix pipe, so their latency
+            // overlaps the softmax and the PV product instead of stalling the next tile.
+            auto er_load = [&](int c, float4 (&ef)[NS]) {
                 int row = p.er_len - 1 - (32 * c + li);
                 row = max(0, min(p.er_len - 1, row));      // out-of-range rows belong to masked pairs
                 const float* ep = p.Er + (size_t)row * HD + 4 * lh;
-                float4 ef[NS];
 #pragma unroll
                 for (int s = 0; s < NS; ++s) ef[s] = ld4(ep + 8 * s);
+            };
+            auto chunk = [&](int c, const float4 (&ef)[NS]) {
                 f32x16 racc;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) racc[e] = 0.f;
@@ -141,8 +154,15 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) slot[li * 33 + (e & 3) + 8 * (e >> 2) + 4 * lh] = racc[e];
             };
-            if (kt == 0) chunk(k);                          // first tile of this wave's row block: both chunks are new
-            if (k >= 1) chunk(k - 1);
+            if (!er_primed) {                                // first tile this wave computes: both chunks are new
+                float4 e0[NS];
+                er_load(k, e0);
+                chunk(k, e0);
+                er_load(k - 1, er_next);
+                er_primed = true;
+            }
+            if (k >= 1) chunk(k - 1, er_next);
+            if (k >= 2) er_load(k - 2, er_next);             // for the next tile (it reads chunk k-2 as its k-1)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int krow = (e & 3) + 8 * (e >> 2) + 4 * lh;
@@ -154,11 +174,16 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
 
         // ---- mask + online softmax (one query per lane, keys split over the two lane halves) ----
         float tmax = -INFINITY;
+        if (j0 + KT <= p.Lk && (!p.causal || j0 + KT - 1 <= i0)) {      // the whole tile is visible to every query of the wave
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int j = j0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            if (j >= p.Lk || (p.causal && j > iq)) sacc[e] = -INFINITY;
-            tmax = fmaxf(tmax, sacc[e]);
+            for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int j = j0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (j >= p.Lk || (p.causal && j > iq)) sacc[e] = -INFINITY;
+                tmax = fmaxf(tmax, sacc[e]);
+            }
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);
@@ -210,7 +235,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
 
 template <int HD>
 int32_t launch_hd(const AttnParams& p, hipStream_t stream) {
-    dim3 grid(cdiv(p.Lq, QB), p.H, p.B);
+    dim3 grid(cdiv(p.Lq, QB) * p.H * p.B);
     if (p.Er) hipLaunchKernelGGL((attn_prefill_kernel<HD, true>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((attn_prefill_kernel<HD, false>), grid, dim3(256), 0, stream, p);
     return 0;
