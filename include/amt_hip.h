@@ -269,6 +269,16 @@ int32_t amt_v2_step_batch(const void* const* tab, int32_t n_layers, int32_t H, i
                           int32_t S, int32_t max_seq, int32_t B, const float* keys_dev, int32_t* state_dev,
                           float* logits_out, float* ws, void* stream);
 
+/* Per-clip decision of the lockstep step, on the device (reference model/video_music_transformer.py:547-600: temperature
+ * softmax[:157], N / repeat suppression, top-1 / arg-max / Categorical draw by inverse CDF at uniforms[(pos)*B + b], id ->
+ * (root, attr) feedback; chord_embed: the id feeds back).  Launch right after amt_v2_step_batch on the same stream (it
+ * reads the position from state_dev[0], which that call has advanced): stores tokens[b][pos] (and roots / attrs, all
+ * [B][T] int64, primer positions pre-filled) and leaves the position's (root, attr) in state_dev for the next step.
+ * No host round trip: the pair (step, decide) is captured once and replayed T-1 times. */
+int32_t amt_v2_decide_batch(const float* logits, int32_t ld_logits, int32_t* state_dev, int64_t* tokens, int64_t* roots,
+                            int64_t* attrs, int32_t B, int32_t T, int32_t n_primer, int32_t beam, int32_t max_conseq_N,
+                            int32_t max_conseq_chord, float temperature, const float* uniforms, int32_t chord_embed, void* stream);
+
 /* ---- regression head VideoRegression(regModel='bimamba+') (model/video_regression.py:104-245) ---- */
 /* Depthwise causal Conv1d(kernel K, padding K-1)[..., :L] + SiLU of MambaBlock.forward (mamba.py:172-175,268-272):
  * x (B,L,C) with row stride ldx, w (C,K) = conv1d.weight (C,1,K), y (B,L,C).  reverse = 1 evaluates the block of the

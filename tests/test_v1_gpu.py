@@ -111,7 +111,17 @@ def test_lockstep_generate_batch_equals_per_clip_generate(make, B, P):
                 one = m.generate(f["semantic"][c:c + 1], f["key"][c], f["scene_offset"][c:c + 1], f["motion"][c:c + 1], f["emotion"][c:c + 1],
                                  pr[0][c], pr[1][c], pr[2][c], target_seq_length=T, **kw)
                 assert torch.equal(one[0], got[c]), (kw, c)
+        dev_ids = m.generate_batch(*args, *pr, target_seq_length=T, beam=0, sampler="argmax")
         eager = m.generate_batch(*args, *pr, target_seq_length=T, beam=0, sampler="argmax", use_graph=False)
-        assert torch.equal(eager, m.generate_batch(*args, *pr, target_seq_length=T, beam=0, sampler="argmax"))
+        assert torch.equal(eager, dev_ids)
+        # the round-1 loop with the decision on the host gives the same ids as the on-device decision
+        assert torch.equal(m.generate_batch(*args, *pr, target_seq_length=T, beam=0, sampler="argmax", decision="host"), dev_ids)
         rnd = m.generate_batch(*args, pr[0][0], pr[1][0], pr[2][0], target_seq_length=T, beam=0)       # shared primer, random draw
         assert rnd.shape == (B, T) and int(rnd[:, P:].min()) >= 1 and int(rnd.max()) < 157
+        assert not bool(((rnd[:, 2:] == rnd[:, 1:-1]) & (rnd[:, 1:-1] == rnd[:, :-2]))[:, max(P - 2, 0):].any())   # repeat suppression
+        # the device draw is the inverse CDF at the supplied uniforms: same uniforms -> same ids; u = 0 -> the lowest allowed ids
+        u = torch.rand(T, B, generator=torch.Generator().manual_seed(3))
+        a = m.generate_batch(*args, pr[0][0], pr[1][0], pr[2][0], target_seq_length=T, beam=0, uniforms=u)
+        assert torch.equal(a, m.generate_batch(*args, pr[0][0], pr[1][0], pr[2][0], target_seq_length=T, beam=0, uniforms=u))
+        lo = m.generate_batch(*args, pr[0][0], pr[1][0], pr[2][0], target_seq_length=T, beam=0, uniforms=torch.zeros(T, B))
+        assert set(lo[:, P + 1:].flatten().tolist()) <= {1, 2}

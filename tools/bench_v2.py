@@ -29,7 +29,12 @@ with torch.no_grad():
         torch.cuda.synchronize(); t0 = time.perf_counter()
         ob = m.generate_batch(*args, target_seq_length=300, beam=0, sampler="argmax")
         torch.cuda.synchronize(); db = time.perf_counter() - t0
-        batch[f"B{nb}"] = {"s": round(db, 3), "tokens_per_s": round(nb * 299 / db, 1), "ms_per_step": round(db / 299 * 1e3, 3)}
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        oh = m.generate_batch(*args, target_seq_length=300, beam=0, sampler="argmax", decision="host")
+        torch.cuda.synchronize(); dh = time.perf_counter() - t0
+        assert torch.equal(ob, oh)
+        batch[f"B{nb}"] = {"s": round(db, 3), "tokens_per_s": round(nb * 299 / db, 1), "ms_per_step": round(db / 299 * 1e3, 3),
+                           "host_decision_s": round(dh, 3), "host_decision_tokens_per_s": round(nb * 299 / dh, 1)}
 print(json.dumps({"v2_generate_T300_s": round(dt, 3), "tokens_per_s": round(299 / dt, 1), "unique_ids": len(set(out.flatten().tolist())),
                   "v2_forward_B8_L300_ms": round(df * 1e3, 2),
                   "v2_generate_batch_T300": batch}))

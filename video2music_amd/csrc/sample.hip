@@ -441,6 +441,80 @@ __global__ __launch_bounds__(256) void embed_step_kernel(SampleParams p, int adv
 
 }  // namespace
 
+namespace {
+
+// Decision of the lockstep V1 / V2 / V3-family step (model/video_music_transformer.py:547-600 of the reference, per clip):
+// probs = softmax(logits / temperature)[:157]; beam == 1: top-1, no feedback of root / attr; beam == 0: N / repeat
+// suppression, arg-max of the re-normalised probabilities (oracle G2) or the inverse-CDF draw at the supplied uniform
+// (Categorical.sample), token -> (root, attr) by the chord.json rule (chord_embed: the id itself feeds back).  One wave per
+// clip.  Runs right after amt_v2_step_batch in the same captured graph: state[0] already points at the position being
+// decided; the kernel stores the token and leaves that position's (root, attr) in state[1+b], state[1+B+b] for the next step.
+__global__ __launch_bounds__(64) void v2_decide_kernel(const float* __restrict__ logits, int ld_logits, int32_t* __restrict__ state,
+                                                      int64_t* __restrict__ tokens, int64_t* __restrict__ roots, int64_t* __restrict__ attrs,
+                                                      int B, int T, int n_primer, int beam, int max_conseq_N, int max_conseq_chord,
+                                                      float inv_temperature, const float* __restrict__ uniforms, int chord_embed) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int cur = state[0];                                  // position decided now (its predecessor's logits are in `logits`)
+    if (cur >= T) return;
+    if (cur >= n_primer) {
+        const float* lg = logits + (size_t)b * ld_logits;
+        float z[3];
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int n = lane + 64 * k;
+            z[k] = n < V ? lg[n] * inv_temperature : -INFINITY;
+            m = fmaxf(m, z[k]);
+        }
+        m = wave_max(m);
+        float pr[3];
+        float ps = 0.f;
+        const int64_t prev = tokens[(size_t)b * T + cur - 1];
+        bool rep = beam == 0 && cur >= max_conseq_chord;
+        for (int k = 1; rep && k < max_conseq_chord; ++k) rep = tokens[(size_t)b * T + cur - 1 - k] == prev;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int n = lane + 64 * k;
+            float e = n < VP ? __expf(z[k] - m) : 0.f;         // the softmax denominator cancels in both decisions
+            if (beam == 0 && ((max_conseq_N == 0 && n == 0) || (rep && n == (int)prev))) e = 0.f;
+            pr[k] = e;
+            ps += e;
+        }
+        ps = wave_sum(ps);
+        SampleParams sp{};
+        sp.beam = beam; sp.uniforms = uniforms; sp.B = B;
+        const int tok = pick_token(sp, pr, ps, lane, b, cur - 1);
+        if (lane == 0) {
+            tokens[(size_t)b * T + cur] = tok;
+            int root = ROOT_PAD, attr = ATTR_PAD;              // beam == 1: the generated ids never feed back (:547-560)
+            if (chord_embed) { root = tok; attr = 0; }
+            else if (beam == 0) { root = tok == 0 ? 0 : (tok - 1) / 13 + 1; attr = tok == 0 ? 1 : (tok - 1) % 13 + 1; }
+            roots[(size_t)b * T + cur] = root;
+            attrs[(size_t)b * T + cur] = attr;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        state[1 + b] = (int32_t)roots[(size_t)b * T + cur];
+        state[1 + B + b] = (int32_t)attrs[(size_t)b * T + cur];
+    }
+}
+
+}  // namespace
+
+extern "C" int32_t amt_v2_decide_batch(const float* logits, int32_t ld_logits, int32_t* state_dev, int64_t* tokens, int64_t* roots,
+                                       int64_t* attrs, int32_t B, int32_t T, int32_t n_primer, int32_t beam, int32_t max_conseq_N,
+                                       int32_t max_conseq_chord, float temperature, const float* uniforms, int32_t chord_embed,
+                                       void* stream) {
+    AMT_CHECK_ARG(logits && state_dev && tokens && roots && attrs, "amt_v2_decide_batch: null pointer");
+    AMT_CHECK_ARG(B > 0 && T > 1 && n_primer >= 1 && n_primer <= T && ld_logits >= 159, "amt_v2_decide_batch: bad shape");
+    AMT_CHECK_ARG((beam == 0 || beam == 1) && max_conseq_chord >= 1 && temperature > 0.f, "amt_v2_decide_batch: bad decision parameters");
+    hipLaunchKernelGGL(v2_decide_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, logits, ld_logits, state_dev, tokens, roots, attrs, B, T,
+                       n_primer, beam, max_conseq_N, max_conseq_chord, 1.0f / temperature, uniforms, chord_embed);
+    AMT_LAUNCH_CHECK();
+    return 0;
+}
+
 int32_t amt_launch_sample(const SampleParams& p, hipStream_t stream) {
     AMT_CHECK_ARG(p.B > 0 && p.d % 4 == 0 && p.d <= 1024, "sample: bad shape B=%d d=%d", p.B, p.d);
     if (p.lraw) {

@@ -877,14 +877,20 @@ class VideoMusicTransformer_V2(nn.Module):
 
     def generate_batch(self, feature_semantic_list, feature_key, feature_scene_offset, feature_motion, feature_emotion,
                        primer, primer_root, primer_attr, target_seq_length=300, beam=0, beam_chance=1.0, max_conseq_N=0,
-                       max_conseq_chord=2, temperature=1.0, sampler="categorical", use_graph=True):
+                       max_conseq_chord=2, temperature=1.0, sampler="categorical", use_graph=True, decision="device",
+                       uniforms=None):
         """`generate` for B clips at once -> LongTensor (B, T); row b equals `generate` on clip b alone (the reference
         generates one clip per call).  Features (B, S, .), key (B,) / (B, 1); primers (P,) shared or (B, P).
 
         The clips advance in lockstep through one captured step graph (`amt_v2_step_batch`): each projection reads its
         weights once per step for all clips.  The video encoder runs once over all clips as independent batches of one (for B > 1
-        the reference's raw RoPE view would tie the clips of a batch together); the per-step decision runs on the host as in
-        `generate`."""
+        the reference's raw RoPE view would tie the clips of a batch together).
+
+        ``decision="device"`` (default): the per-step decision of the reference loop (:547-600: temperature softmax[:157],
+        suppression, top-1 / arg-max / Categorical draw, root / attr feedback) runs in `amt_v2_decide_batch` inside the same
+        captured graph, so a generate is T-1 graph replays with no host round trip; the Categorical draw is the inverse CDF at
+        ``uniforms`` (T, B) (default ``torch.rand`` on the device: ``torch.manual_seed`` repeats a run).  ``decision="host"``
+        keeps the round-1 loop (logits copied to the host every step, torch's own Categorical)."""
         from ..utilities.constants import chord_to_root_attr
         assert (not self.training), "Cannot generate while in training mode"
         if beam not in (0, 1):
@@ -915,6 +921,11 @@ class VideoMusicTransformer_V2(nn.Module):
                                   temperature=temperature, sampler=sampler, use_graph=use_graph) for c in range(nb)]
             return torch.cat(rows)
         keys = key.to(dev)
+        if decision not in ("device", "host"):
+            raise ValueError(f"unknown decision {decision!r}")
+        if decision == "device":
+            return self._lockstep_device(st, keys, gen, gen_root, gen_attr, nb, T, P, beam, max_conseq_N, max_conseq_chord,
+                                         temperature, sampler, use_graph, uniforms)
         state = torch.zeros(1 + 2 * nb, dtype=torch.int32, device=dev)
         ra_table = torch.tensor([chord_to_root_attr(i) for i in range(CHORD_END)])          # id -> (root, attr) feedback (:578-597)
 
@@ -944,6 +955,41 @@ class VideoMusicTransformer_V2(nn.Module):
                                        max_conseq_chord, temperature, sampler).to(dev)
         finally:
             torch.set_num_threads(n_threads)
+
+    def _lockstep_device(self, st, keys, gen, gen_root, gen_attr, nb, T, P, beam, max_conseq_N, max_conseq_chord, temperature,
+                         sampler, use_graph, uniforms):
+        """Lockstep generate with the decision on the device: (amt_v2_step_batch, amt_v2_decide_batch) for position 0 issued
+        eagerly, then that pair captured once and replayed for positions 1 .. T-2; one synchronisation at the end."""
+        dev = keys.device
+        if sampler not in ("categorical", "argmax"):
+            raise ValueError(f"unknown sampler {sampler!r}")
+        tokens, roots, attrs = gen.to(dev).contiguous(), gen_root.to(dev).contiguous(), gen_attr.to(dev).contiguous()
+        unif = None
+        if beam == 0 and sampler == "categorical":
+            unif = (torch.rand(T, nb, device=dev) if uniforms is None else torch.as_tensor(uniforms, dtype=torch.float32).to(dev)).contiguous()
+            assert unif.shape == (T, nb), "uniforms must be (target_seq_length, B)"
+        state = torch.zeros(1 + 2 * nb, dtype=torch.int32, device=dev)
+        state[1:] = torch.cat((gen_root[:, 0], gen_attr[:, 0])).to(torch.int32)
+
+        def pair():
+            self._step_batch(st, keys, state)
+            _lib.call("amt_v2_decide_batch", _lib.ptr(st["logits"]), CHORD_SIZE, _lib.ptr(state), _lib.ptr(tokens), _lib.ptr(roots),
+                      _lib.ptr(attrs), nb, T, P, int(beam), int(max_conseq_N), int(max_conseq_chord), float(temperature),
+                      _lib.ptr(unif), int(bool(self.chord_embed)), _lib.stream_ptr())
+
+        pair()                                                          # position 0 (the warm-up a capture needs)
+        if T > 2:
+            if use_graph:
+                torch.cuda.current_stream().synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with _CAPTURE_LOCK, torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    pair()
+                for _ in range(T - 2):
+                    graph.replay()
+            else:
+                for _ in range(T - 2):
+                    pair()
+        return tokens
 
     def _lockstep_loop(self, next_logits, gen, gen_root, gen_attr, ra_table, nb, T, P, beam, max_conseq_N, max_conseq_chord,
                        temperature, sampler):
