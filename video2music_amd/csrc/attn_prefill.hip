@@ -233,9 +233,154 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     }
 }
 
+// Split-key variant for small grids (few clips x heads x query blocks: MultiheadGQA at config 4 has 128 of the 128-row blocks
+// for 256 CUs, and the last causal block alone walks 64 key tiles).  A workgroup owns ONE 32-query row block; its 4 waves
+// take the key tiles round-robin (wave w: tiles w, w+4, ...), each staging its own tiles in its own LDS region -- no barrier
+// in the loop --, and the 4 partial softmax states (m, l, O) are merged through LDS at the end.  Grid = 4x the blocks of the
+// 128-row kernel and a critical path 4x shorter; K/V tiles are read once per 32 query rows instead of once per 128 (L2
+// traffic the large-grid shapes would not want).  No relative-position term.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_prefill_splitk_kernel(AttnParams p) {
+    constexpr int LD = HD + 4, NS = HD / 8, ND = HD / 32;
+    constexpr int TILE = KT * LD;
+    __shared__ __attribute__((aligned(16))) float KV[4][2 * TILE];      // per wave: K tile | V tile; reused for the merge
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int n_bh = p.H * p.B, n_qb = (p.Lq + 31) / 32;
+    const int qblk = n_qb - 1 - (int)(blockIdx.x / n_bh);               // heaviest causal row blocks first
+    const int bh = blockIdx.x % n_bh;
+    const int h = bh % p.H, b = bh / p.H;
+    const int hk = h / p.kv_group;
+    const int i0 = qblk * 32, iq = i0 + li;
+    float* Ks = KV[wave];
+    float* Vs = KV[wave] + TILE;
+
+    const float* qp = p.q + (size_t)b * p.q_bs + (size_t)h * p.q_hs;
+    const float* kp = p.k + (size_t)b * p.k_bs + (size_t)hk * p.k_hs;
+    const float* vp = p.v + (size_t)b * p.v_bs + (size_t)hk * p.v_hs;
+    const float qs = p.q_scale == 0.f ? 1.f : p.q_scale;
+    float qreg[HD / 2];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        float4 t = (iq < p.Lq) ? ld4(qp + (size_t)iq * p.q_ls + 8 * s + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
+        qreg[4 * s + 0] = t.x * qs; qreg[4 * s + 1] = t.y * qs; qreg[4 * s + 2] = t.z * qs; qreg[4 * s + 3] = t.w * qs;
+    }
+    f32x16 oacc[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    int k_end = p.Lk;
+    if (p.causal) k_end = min(p.Lk, i0 + 32);
+    const int n_tiles = (k_end + KT - 1) / KT;
+
+    // one wave stages a whole tile: 32 rows x HD/4 float4 per tensor over 64 lanes
+    constexpr int F4_ROW = HD / 4, PER_W = KT * F4_ROW / 64;
+    float4 kst[PER_W], vst[PER_W];
+    auto gload = [&](int j0) {
+#pragma unroll
+        for (int i = 0; i < PER_W; ++i) {
+            const int f = lane + i * 64;
+            const int r = f / F4_ROW, c = (f - r * F4_ROW) * 4;
+            const int j = j0 + r;
+            const bool ok = j < p.Lk;
+            kst[i] = ok ? ld4(kp + (size_t)j * p.k_ls + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            vst[i] = ok ? ld4(vp + (size_t)j * p.v_ls + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (wave < n_tiles) gload(wave * KT);
+    for (int kt = wave; kt < n_tiles; kt += 4) {
+        const int j0 = kt * KT;
+#pragma unroll
+        for (int i = 0; i < PER_W; ++i) {
+            const int f = lane + i * 64;
+            const int r = f / F4_ROW, c = (f - r * F4_ROW) * 4;
+            st4(&Ks[r * LD + c], kst[i]);
+            st4(&Vs[r * LD + c], vst[i]);
+        }
+        if (kt + 4 < n_tiles) gload(j0 + 4 * KT);
+        f32x16 sacc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float4 a = ld4(&Ks[li * LD + 8 * s + 4 * lh]);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * s + 0], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * s + 1], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * s + 2], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * s + 3], sacc, 0, 0, 0);
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int j = j0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (j >= p.Lk || (p.causal && j > iq)) sacc[e] = -INFINITY;
+            tmax = fmaxf(tmax, sacc[e]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __expf(m_run - m_use);
+        float psum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            sacc[e] = __expf(sacc[e] - m_use);
+            psum += sacc[e];
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int krow = (e & 3) + 8 * (e >> 2) + 4 * lh;
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt) {
+                const float a = Vs[krow * LD + dt * 32 + li];
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, sacc[e], oacc[dt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- merge the 4 waves' states: partial O (un-normalised, [query][d]) | m | l in the wave's own LDS region ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float* mg = KV[wave];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mg[li * (HD + 1) + dt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh] = oacc[dt][e];
+    if (lh == 0) { mg[32 * (HD + 1) + li] = m_run; mg[32 * (HD + 1) + 32 + li] = l_tot; }
+    __syncthreads();
+    float* op = p.o + (size_t)b * p.o_bs + (size_t)h * p.o_hs;
+    for (int f = tid; f < 32 * HD; f += 256) {
+        const int r = f / HD, c = f - r * HD;
+        if (i0 + r >= p.Lq) continue;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) mx = fmaxf(mx, KV[w][32 * (HD + 1) + r]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float mw = KV[w][32 * (HD + 1) + r];
+            const float a = (mw == -INFINITY) ? 0.f : __expf(mw - mx);
+            num += a * KV[w][r * (HD + 1) + c];
+            den += a * KV[w][32 * (HD + 1) + 32 + r];
+        }
+        op[(size_t)(i0 + r) * p.o_ls + c] = den > 0.f ? num / den : 0.f;
+    }
+}
+
 template <int HD>
 int32_t launch_hd(const AttnParams& p, hipStream_t stream) {
     dim3 grid(cdiv(p.Lq, QB) * p.H * p.B);
+    // fewer than two 128-row blocks per CU and a long key range: one 32-row block per workgroup, keys split over its waves
+    if (!p.Er && HD <= 64 && grid.x < 512 && p.Lk >= 256) {
+        hipLaunchKernelGGL((attn_prefill_splitk_kernel<(HD <= 64 ? HD : 64)>), dim3(cdiv(p.Lq, 32) * p.H * p.B), dim3(256), 0, stream, p);
+        return 0;
+    }
     if (p.Er) hipLaunchKernelGGL((attn_prefill_kernel<HD, true>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((attn_prefill_kernel<HD, false>), grid, dim3(256), 0, stream, p);
     return 0;
