@@ -220,3 +220,23 @@ def test_config2_generate_prefix_vs_reference(golden, which, clip, recipe):
     n = min(first_ill_conditioned(mg) + 1, T)
     assert n == T and np.array_equal(out[0, :n], ids[0, :n])
     assert np.abs(np.array(margins) - mg[:T - 1]).max() < 1e-4
+
+
+@pytest.mark.parametrize("clip", [0, 1])
+def test_v2_well_conditioned_fixture(golden, clip):
+    """g_v2_hi.npz (reference V2 '2.2', "feedback" recipe): every decision's margin >= 1e-2; the oracle reproduces the ids (the
+    oracle's generate has no temperature: the temperature-1.0 run) and the forward logits."""
+    from tests.helpers import CFG_V2, synthetic_sd_v2
+    g = golden("g_v2_hi.npz")
+    assert g[f"g2_t10_margins_clip{clip}"].min() >= 1e-2 and g[f"g2_t08_margins_clip{clip}"].min() >= 1e-2
+    assert len(set(g[f"g2_t10_clip{clip}"].flatten().tolist())) >= 12
+    sd = synthetic_sd_v2(CFG_V2, seed=int(g["seed"]), recipe="feedback")
+    f = feats_t(synthetic.synthetic_features(3, seed=1234), slice(clip, clip + 1), key=g["key"])
+    pr, prr, pra = (torch.tensor([int(v)]) for v in g[f"primer_clip{clip}"])
+    args = (sd, 4, f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], pr, prr, pra)
+    assert np.array_equal(O.generate(*args, target_seq_length=48, beam=0, forward_fn=O.forward_v2).numpy(), g[f"g2_t10_clip{clip}"])
+    assert np.array_equal(O.generate(*args, target_seq_length=48, beam=1, forward_fn=O.forward_v2).numpy(), g[f"g1_clip{clip}"])
+    if clip == 0:
+        lg = O.forward_v2(sd, 4, torch.from_numpy(g["fwd_root"]), torch.from_numpy(g["fwd_attr"]), f["semantic"], f["key"], f["scene_offset"],
+                          f["motion"], f["emotion"])
+        assert np.abs(lg.numpy() - g["fwd_logits"]).max() < 5e-4          # logits of magnitude ~60 with this recipe: 1e-5 relative
