@@ -34,7 +34,9 @@ constexpr unsigned long long SPIN_TICKS = 100ull * 1000;   // 1 ms of s_memrealt
 #ifdef AMT_STAMPS
 #define PSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); st_[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PSTAMP_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define PSTAMP_FLUSH() do { if (P.stamps && threadIdx.x == 0) { for (int i_ = 0; i_ < 8; ++i_) P.stamps[(size_t)blockIdx.x * 8 + i_] = st_[i_]; } } while (0)
+#define PSTAMP_FLUSH() do { if (P.stamps && threadIdx.x == 0) { \
+    st_[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); \
+    for (int i_ = 0; i_ < 8; ++i_) P.stamps[(size_t)blockIdx.x * 8 + i_] = st_[i_]; } } while (0)
 #else
 #define PSTAMP(i) do { } while (0)
 #define PSTAMP_DECL do { } while (0)
@@ -337,11 +339,16 @@ __device__ __forceinline__ void cross_attn_role(const DecodePhaseParams& P, floa
     const int n_keys = p.n_keys;
     PSTAMP_DECL;
     PSTAMP(0);
+    // late start: let the GEMM tiles' own loads get into the memory queues first (pf_rows doubles as the delay, x 0.27 us)
+    for (int i = 0; i < P.pf_rows; ++i) __builtin_amdgcn_s_sleep(10);
     float4 kr[MAXR], vr[MAXR];
+    // paced: at most 16 loads (16 KiB) in flight per wave, as in attn_decode.hip's double-buffered stream -- issuing all 20 at
+    // once (160 KiB per CU) collapsed the stream rate in the first version of this experiment
 #pragma unroll
     for (int r = 0; r < MAXR; ++r) {
         const int j = r * RK + wave * KPW + sub;
         const unsigned off = (unsigned)((j < n_keys ? j : 0) * HD + c4);
+        if (r >= 8) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
         kr[r] = ld4_nt(kb + off);
         vr[r] = ld4_nt(vb + off);
     }

@@ -71,9 +71,11 @@ int main() {
     const int n1 = (2 * d / 16) * 2, na = B * H, n2 = ((d + dff) / 16) * 2;
     unsigned long long *st1, *st2;
     CK(hipMalloc(&st1, (size_t)(n1 + na) * 64)); CK(hipMalloc(&st2, (size_t)n2 * 64));
+    const int delay = getenv("PHASE_DELAY") ? atoi(getenv("PHASE_DELAY")) : 0;
+    printf("attention role start delay: %d x 0.27 us\n", delay);
     bench("fused: phase(G1 + cross-attention) -> phase(G2)", [&](hipStream_t s, int i) {
         const int l = i % nl;
-        DecodePhaseParams p1{}; p1.g = G1[l]; p1.a = X[l]; p1.sync = sync + 4 * l; p1.stamps = st1; amt_launch_decode_phase(p1, s);
+        DecodePhaseParams p1{}; p1.g = G1[l]; p1.a = X[l]; p1.sync = sync + 4 * l; p1.stamps = st1; p1.pf_rows = delay; amt_launch_decode_phase(p1, s);
         DecodePhaseParams p2{}; p2.g = G2[l]; p2.stamps = st2; amt_launch_decode_phase(p2, s);
     }, 120, 2);
     unsigned err[64]; CK(hipMemcpy(err, sync, 64 * 4, hipMemcpyDeviceToHost));
@@ -96,6 +98,22 @@ int main() {
     stat("start", h1, n1, n1 + na, 0); stat("K/V prefetch issued", h1, n1, n1 + na, 1); stat("counter satisfied", h1, n1, n1 + na, 2);
     stat("q/u rows read (K/V landed)", h1, n1, n1 + na, 3); stat("scores + PV done", h1, n1, n1 + na, 4); stat("output stored", h1, n1, n1 + na, 5);
     stat("left", h1, n1, n1 + na, 6);
+    {   // placement: HW_ID (reg 4): cu_id bits 8-11, sh_id bit 12, se_id bits 13-15(+); XCC_ID (reg 20) bits 0-3
+        std::vector<int> per_cu_attn(8 * 64, 0), per_cu_gemm(8 * 64, 0);
+        for (int w = 0; w < n1 + na; ++w) {
+            const unsigned long long v = h1[(size_t)w * 8 + 7];
+            const unsigned hw = (unsigned)v, xcc = (unsigned)(v >> 32) & 0xF;
+            const unsigned cu = (hw >> 8) & 0xF, sh = (hw >> 12) & 0x1, se = (hw >> 13) & 0x7;
+            const int id = (int)(xcc * 64 + se * 16 + sh * 0 + cu) % 512;
+            (w < n1 ? per_cu_gemm : per_cu_attn)[id] += 1;
+        }
+        int hist[4][4] = {};
+        int used = 0;
+        for (int i = 0; i < 512; ++i) { if (per_cu_attn[i] + per_cu_gemm[i]) ++used; hist[std::min(per_cu_gemm[i], 3)][std::min(per_cu_attn[i], 3)]++; }
+        printf("placement: %d distinct (xcc,se,cu) ids used; ids with (gemm WGs, attention WGs): ", used);
+        for (int g = 0; g < 4; ++g) for (int a = 0; a < 4; ++a) if (hist[g][a] && (g || a)) printf("(%d,%d)x%d ", g, a, hist[g][a]);
+        printf("\n");
+    }
     unsigned long long t2 = ~0ull, e1 = 0;
     for (int w = 0; w < n1 + na; ++w) e1 = std::max(e1, h1[(size_t)w * 8 + 6]);
     for (int w = 0; w < n1; ++w) e1 = std::max(e1, h1[(size_t)w * 8 + 4]);
