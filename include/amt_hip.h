@@ -99,6 +99,18 @@ int32_t amt_generate_run(amt_handle* h, int32_t n_steps, float* logits_out, void
  * 4: an EMPTY event pair per step = the overhead of the two records, to be subtracted}, the
  * summed pair durations (ms) and counts (arrays of 5), and for classes 0/1 the algorithmic K/V bytes
  * (fp32 K and V rows of the keys each launch must read).  Used by bench.py's roofline leg. */
+/* Options of the base model that change the input tables (before the first amt_finalize).
+ *   "chord_embed" = 1: reference chord_embed=True (model/video_music_transformer.py:931-937, 986-987): the chord id indexes a frozen
+ *   table instead of root + attr embeddings.  The caller uploads that table (n_rows, d) under the name "embedding_root.weight" and
+ *   an all-zero (16, d) "embedding_attr.weight", passes chord ids as the root ids and zeros as the attr ids; the generated id then
+ *   feeds back as the root index in both decision branches. */
+int32_t amt_set_option(amt_handle* h, const char* name, int32_t value);
+/* amt_encode with rows [B*S][d] added to Linear_vis's output before the encoder: reference scene_embed=True
+ * (:1016-1027: the scene offset is left out of the feature columns and scene_embedding(offset.int()) is added instead).  The
+ * caller keeps the scene column in the features and uploads Linear_vis.weight with a zero column at its position. */
+int32_t amt_encode_resid(amt_handle* h, int32_t B, int32_t S, const float* sem, int32_t sem_dim, const float* scene,
+                         const float* motion, int32_t motion_dim, const float* emotion, int32_t emo_dim,
+                         const float* vis_resid, float* memory_out, void* stream);
 int32_t amt_generate_profile(amt_handle* h, int32_t n_steps, double* ms_by_class, int64_t* launches_by_class,
                              int64_t* attn_bytes_by_class, void* stream);
 /* One decode step that stops before the decision: writes the decision distribution

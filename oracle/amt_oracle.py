@@ -146,13 +146,17 @@ def n_layers_of(sd, stack):
 def video_stream(sd, sem, scene_off, motion, emotion):
     """model/video_music_transformer.py:1005-1030: concat features, Linear_vis, + pe_v."""
     vf = sem.to(sd["Linear_vis.weight"].dtype)
-    vf = torch.cat([vf, scene_off.unsqueeze(-1).to(vf.dtype)], dim=-1)
+    scene_embed = "scene_embedding.weight" in sd          # scene_embed=True (:926-928): the offset indexes an embedding instead (:1016-1027)
+    if not scene_embed:
+        vf = torch.cat([vf, scene_off.unsqueeze(-1).to(vf.dtype)], dim=-1)
     if motion.dim() == 2:
         vf = torch.cat([vf, motion.unsqueeze(-1).to(vf.dtype)], dim=-1)
     else:
         vf = torch.cat([vf, motion.to(vf.dtype)], dim=-1)
     vf = torch.cat([vf, emotion.to(vf.dtype)], dim=-1)
     vf = linear(vf, sd["Linear_vis.weight"], sd["Linear_vis.bias"])
+    if scene_embed:
+        vf = vf + sd["scene_embedding.weight"][scene_off.to(torch.int32).long()]
     S, d = vf.shape[1], vf.shape[2]
     return vf + positional_encoding(S, d, vf.dtype)
 
@@ -172,7 +176,10 @@ def encode(sd, H, sem, scene_off, motion, emotion):
 
 def chord_stream(sd, x_root, x_attr, key):
     """model/video_music_transformer.py:984-1001,1027-1029: E_root+E_attr, append key, Linear_chord, + pe."""
-    x = sd["embedding_root.weight"][x_root] + sd["embedding_attr.weight"][x_attr]
+    if "chord_embedding_model.weight" in sd:             # chord_embed=True (:931-937, 986-987): `x_root` carries the chord ids
+        x = sd["chord_embedding_model.weight"][x_root]
+    else:
+        x = sd["embedding_root.weight"][x_root] + sd["embedding_attr.weight"][x_attr]
     B, L, d = x.shape
     key = key.to(x.dtype).reshape(-1)
     if key.numel() == 1:
@@ -231,6 +238,9 @@ def generate(sd, H, sem, key, scene_off, motion, emotion, primer, primer_root, p
     gen[0, :P] = primer
     gen_root[0, :P] = primer_root
     gen_attr[0, :P] = primer_attr
+    ids_feed = "chord_embedding_model.weight" in sd       # chord_embed: forward consumes gen_seq itself, in both branches
+    if ids_feed:
+        gen_root[0, :P] = primer
     cur = P
     while cur < T:
         logits = (forward_fn or forward)(sd, H, gen_root[:, :cur], gen_attr[:, :cur], sem, key, scene_off, motion, emotion)
@@ -239,6 +249,8 @@ def generate(sd, H, sem, key, scene_off, motion, emotion, primer, primer_root, p
         if beam > 0:
             tok = int(torch.topk(probs.flatten(), 1)[1][0]) % CHORD_SIZE
             gen[0, cur] = tok
+            if ids_feed:
+                gen_root[0, cur] = tok
         else:
             if max_conseq_N == 0:
                 probs[0, 0] = 0.0
@@ -253,7 +265,7 @@ def generate(sd, H, sem, key, scene_off, motion, emotion, primer, primer_root, p
             pn = probs / probs.sum(-1, keepdim=True)        # Categorical(probs=...) normalises
             tok = int(pn.argmax(-1))
             probs = pn
-            r, a = root_attr_of(tok)
+            r, a = (tok, 0) if ids_feed else root_attr_of(tok)
             gen[0, cur] = tok
             gen_root[0, cur] = r
             gen_attr[0, cur] = a

@@ -102,8 +102,8 @@ def test_unsupported_constructor_options_raise():
     plain = VideoMusicTransformer(rpr=False, **{k: v for k, v in CFG1.items() if k != "rpr"})       # torch's stock decoder layers: no Er
     assert not any(k.endswith(".Er") for k in plain.state_dict())
     assert len(plain.state_dict()) == len(VideoMusicTransformer(**CFG1).state_dict()) - CFG1["n_layers"]
-    with pytest.raises(NotImplementedError):
-        VideoMusicTransformer(total_vf_dim=1287, rpr=True, chord_embed=True)
+    both = VideoMusicTransformer(total_vf_dim=1286, rpr=True, chord_embed=True, scene_embed=True)   # round 2: built (:926-937)
+    assert {"chord_embedding_model.weight", "scene_embedding.weight"} <= set(both.state_dict())
 
 
 def test_no_cpu_fallback():

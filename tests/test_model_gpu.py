@@ -516,3 +516,34 @@ def test_feedback_recipe_generate_hi_entropy_vs_reference_golden(golden, clip):
         with torch.no_grad():
             lg = m(torch.zeros_like(root), root, attr, f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"])
         assert np.abs(lg.cpu().numpy() - g["fwd_logits"]).max() < LOGIT_TOL
+
+
+@pytest.mark.parametrize("tag", ["ce", "se", "cese"])
+def test_base_model_chord_embed_scene_embed_vs_reference_golden(golden, tag):
+    """chord_embed=True (chord ids through a frozen table; the ids feed back in both decision branches) and scene_embed=True
+    (scene offsets through an embedding instead of a feature column) of the base class, :926-937,986-987,1016-1027."""
+    from tests.test_oracle_golden import base_embed_sd
+    g = golden("g_base_embed.npz")
+    cfg, sd, ce, se = base_embed_sd(tag)
+    m = VideoMusicTransformer(**cfg, chord_embed=ce, scene_embed=se).eval()
+    assert len(m.state_dict()) == int(g[f"{tag}_n_keys"])
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith(".pe") for k in missing), (missing, unexpected)
+    m = m.cuda()
+    for B in (1, 2):
+        f = cu(feats_t(synthetic.synthetic_features(3, seed=1234), slice(0, B), key=g["key"]))
+        ids, root, attr = (torch.from_numpy(g[f"{tag}_{k}_B{B}"]).cuda() for k in ("x", "root", "attr"))
+        with torch.no_grad():
+            lg = m(ids, root, attr, f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"])
+        assert np.abs(lg.cpu().numpy() - g[f"{tag}_logits_B{B}"]).max() < LOGIT_TOL
+    f = cu(feats_t(synthetic.synthetic_features(3, seed=1234), slice(0, 1), key=g["key"]))
+    kw = dict(feature_semantic_list=f["semantic"], feature_key=f["key"][0], feature_scene_offset=f["scene_offset"], feature_motion=f["motion"],
+              feature_emotion=f["emotion"], primer=torch.tensor([1]), primer_root=torch.tensor([1]), primer_attr=torch.tensor([0]),
+              target_seq_length=32)
+    assert np.array_equal(m.generate(beam=1, **kw).cpu().numpy(), g[f"{tag}_g1"])
+    assert np.array_equal(m.generate(beam=0, sampler="argmax", **kw).cpu().numpy(), g[f"{tag}_g2"])
+    # inside a batch of three (other clips alongside) the clip keeps its ids
+    f3 = cu(feats_t(synthetic.synthetic_features(3, seed=1234), key=g["key"]))
+    toks = m.generate_batch(f3["semantic"], f3["key"], f3["scene_offset"], f3["motion"], f3["emotion"], torch.tensor([1]), torch.tensor([1]),
+                            torch.tensor([0]), target_seq_length=32, beam=0, sampler="argmax")
+    assert np.array_equal(toks[0].cpu().numpy(), g[f"{tag}_g2"][0])

@@ -240,3 +240,36 @@ def test_v2_well_conditioned_fixture(golden, clip):
         lg = O.forward_v2(sd, 4, torch.from_numpy(g["fwd_root"]), torch.from_numpy(g["fwd_attr"]), f["semantic"], f["key"], f["scene_offset"],
                           f["motion"], f["emotion"])
         assert np.abs(lg.numpy() - g["fwd_logits"]).max() < 5e-4          # logits of magnitude ~60 with this recipe: 1e-5 relative
+
+
+def base_embed_sd(tag):
+    """state_dict of the base model with chord_embed / scene_embed as oracle/make_goldens_base_embed.py builds the reference."""
+    from tests.helpers import CFG1
+    from video2music_amd.utilities.constants import SCENE_OFFSET_MAX
+    ce, se = "ce" in tag, "se" in tag
+    cfg = dict(CFG1, total_vf_dim=CFG1["total_vf_dim"] - int(se))
+    sd = dict(synthetic_sd(cfg))
+    if se:
+        sd["scene_embedding.weight"] = torch.from_numpy(synthetic.fill_tensor("scene_embedding.weight", (SCENE_OFFSET_MAX, cfg["d_model"]), 0))
+    if ce:
+        sd["chord_embedding_model.weight"] = torch.from_numpy(synthetic.fill_tensor("chord_embedding_model.weight", (159, cfg["d_model"]), 0))
+    return cfg, sd, ce, se
+
+
+@pytest.mark.parametrize("tag", ["ce", "se", "cese"])
+def test_base_model_chord_embed_scene_embed(golden, tag):
+    """Reference VideoMusicTransformer with chord_embed / scene_embed (model/video_music_transformer.py:926-937,986-987,1016-1027)."""
+    g = golden("g_base_embed.npz")
+    cfg, sd, ce, se = base_embed_sd(tag)
+    assert len(sd) + 2 == int(g[f"{tag}_n_keys"])            # + the two positional-encoding buffers
+    for B in (1, 2):
+        f = feats_t(synthetic.synthetic_features(3, seed=1234), slice(0, B), key=g["key"])
+        ids, root, attr = (torch.from_numpy(g[f"{tag}_{k}_B{B}"]) for k in ("x", "root", "attr"))
+        lg = O.forward(sd, 4, ids if ce else root, attr, f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"])
+        assert np.abs(lg.numpy() - g[f"{tag}_logits_B{B}"]).max() < TOL
+    f = feats_t(synthetic.synthetic_features(3, seed=1234), slice(0, 1), key=g["key"])
+    args = (sd, 4, f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], torch.tensor([1]), torch.tensor([1]), torch.tensor([0]))
+    assert np.array_equal(O.generate(*args, target_seq_length=32, beam=1).numpy(), g[f"{tag}_g1"])
+    margins = []
+    assert np.array_equal(O.generate(*args, target_seq_length=32, beam=0, margins=margins).numpy(), g[f"{tag}_g2"])
+    assert np.abs(np.array(margins) - g[f"{tag}_g2_margins"]).max() < 1e-4 and min(margins) > 1e-2

@@ -34,6 +34,8 @@ SIGNATURES = {
     "amt_load_weight": [_P, C.c_char_p, _P, _I, C.POINTER(C.c_int64)],
     "amt_finalize": [_P],
     "amt_encode": [_P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P],
+    "amt_encode_resid": [_P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P],
+    "amt_set_option": [_P, C.c_char_p, _I],
     "amt_prefill": [_P, _I, _I, _P, _P, _P, _P, _P, _I, _P],
     "amt_generate_begin": [_P, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P],
     "amt_generate_set_uniforms": [_P, _P, _P],

@@ -100,6 +100,9 @@ struct amt_handle {
     int64_t *tokens = nullptr, *roots = nullptr, *attrs = nullptr;   // [maxB][Tcap]
     // current generation
     int genB = 0, genT = 0, genP = 0, beam = 0, mcN = 0, mcC = 2, steps_done = 0;
+    int n_root = 15;                     // rows of the "root" input table: 15 chord roots, or the chord-embedding table's rows (chord_embed)
+    bool chord_embed = false;            // amt_set_option("chord_embed"): the chord id is the input index and feeds back
+    const float* vis_resid = nullptr;    // amt_encode_resid: rows added to Linear_vis's output (scene_embed)
     int skip_mask = 0;                   // bench-only ablation: 1 = no self-attention launches, 2 = no cross-attention launches
     bool gen_active = false;
     // graphs keyed by the parameters baked into the captured kernel arguments
@@ -211,7 +214,7 @@ SampleParams sample_params(amt_handle* h, float* logits_out, float* probs_out, i
     p.max_conseq_N = h->mcN; p.max_conseq_chord = h->mcC;
     p.logits_out = logits_out; p.probs_out = probs_out;
     p.key = h->keyb; p.PR = h->PR; p.PA = h->PA; p.wkey = h->wkey; p.cbias = W(h, "Linear_chord.bias"); p.pe = h->pe;
-    p.x_next = h->x_in; p.sample_external = external;
+    p.x_next = h->x_in; p.sample_external = external; p.chord_embed = h->chord_embed ? 1 : 0;
     p.uniforms = h->use_unif ? h->unif : nullptr;
     if (h->fold) {
         p.lraw = h->lraw; p.ld_lraw = VS; p.h1 = h->vs; p.h2 = h->vs + VS; p.h3 = h->vs + 3 * VS; p.h4 = h->vs + 4 * VS;
@@ -483,7 +486,15 @@ extern "C" int32_t amt_finalize(amt_handle* h) {
     if ((rc = need(h, "Linear_vis.bias", {d}, &bvis))) return rc;
     if ((rc = need(h, "Linear_chord.weight", {d, d + 1}, &Wc))) return rc;
     if ((rc = need(h, "Linear_chord.bias", {d}, &bc))) return rc;
-    if ((rc = need(h, "embedding_root.weight", {15, d}, &Eroot))) return rc;
+    {   // 15 chord roots, or (chord_embed) the frozen chord table uploaded under this name: any number of rows
+        auto it = h->w.find("embedding_root.weight");
+        AMT_CHECK_ARG(it != h->w.end() && it->second.shape.size() == 2, "weight 'embedding_root.weight' was not loaded");
+        const int rows = (int)it->second.shape[0];
+        AMT_CHECK_ARG(h->chord_embed ? rows >= 1 : rows == 15, "embedding_root.weight has %d rows (15 roots, or a chord table with chord_embed)", rows);
+        AMT_CHECK_ARG(!h->KVx || rows == h->n_root, "embedding_root.weight changed its row count (%d -> %d) after the first finalize", h->n_root, rows);
+        h->n_root = rows;
+    }
+    if ((rc = need(h, "embedding_root.weight", {(int64_t)h->n_root, d}, &Eroot))) return rc;
     if ((rc = need(h, "embedding_attr.weight", {16, d}, &Eattr))) return rc;
     if ((rc = need(h, "Wout.weight", {V, d}, &Wout))) return rc;
     if ((rc = need(h, "Wout.bias", {V}, &bout))) return rc;
@@ -546,7 +557,7 @@ extern "C" int32_t amt_finalize(amt_handle* h) {
         if ((rc = dev_alloc(h, &h->Wvis_pad, (size_t)d * h->Fpad))) return rc;
         if ((rc = dev_alloc(h, &h->Wc_main, (size_t)d * d))) return rc;
         if ((rc = dev_alloc(h, &h->wkey, (size_t)d))) return rc;
-        if ((rc = dev_alloc(h, &h->PR, (size_t)15 * d))) return rc;
+        if ((rc = dev_alloc(h, &h->PR, (size_t)h->n_root * d))) return rc;
         if ((rc = dev_alloc(h, &h->PA, (size_t)16 * d))) return rc;
         const size_t bd = (size_t)32 * d;
         if ((rc = dev_alloc(h, &h->x_in, bd))) return rc;
@@ -574,7 +585,7 @@ extern "C" int32_t amt_finalize(amt_handle* h) {
             if ((rc = dev_alloc(h, &h->tWs2, (size_t)VS * d))) return rc;
             if ((rc = dev_alloc(h, &h->vs, (size_t)6 * VS))) return rc;
             if ((rc = dev_alloc(h, &h->lraw, (size_t)32 * VS))) return rc;
-            if ((rc = dev_alloc(h, &h->tab_r, (size_t)15 * 3 * d))) return rc;
+            if ((rc = dev_alloc(h, &h->tab_r, (size_t)h->n_root * 3 * d))) return rc;
             if ((rc = dev_alloc(h, &h->tab_a, (size_t)16 * 3 * d))) return rc;
             if ((rc = dev_alloc(h, &h->tab_k, (size_t)3 * d))) return rc;
             if ((rc = dev_alloc(h, &h->tab_cb, (size_t)3 * d))) return rc;
@@ -597,7 +608,7 @@ extern "C" int32_t amt_finalize(amt_handle* h) {
     AMT_HIP(hipMemcpy2D(h->Wc_main, d * sizeof(float), Wc, (d + 1) * sizeof(float), d * sizeof(float), d, hipMemcpyDeviceToDevice));
     AMT_HIP(hipMemcpy2D(h->wkey, sizeof(float), Wc + d, (d + 1) * sizeof(float), sizeof(float), d, hipMemcpyDeviceToDevice));
     // PR = E_root . Wc_main^T, PA = E_attr . Wc_main^T
-    if ((rc = amt_launch_gemm(gemm_params(Eroot, (int)d, h->Wc_main, (int)d, h->PR, (int)d, 15, (int)d, (int)d, nullptr), s))) return rc;
+    if ((rc = amt_launch_gemm(gemm_params(Eroot, (int)d, h->Wc_main, (int)d, h->PR, (int)d, h->n_root, (int)d, (int)d, nullptr), s))) return rc;
     if ((rc = amt_launch_gemm(gemm_params(Eattr, (int)d, h->Wc_main, (int)d, h->PA, (int)d, 16, (int)d, (int)d, nullptr), s))) return rc;
     for (int l = 0; l < h->nl; ++l) {
         DecLayer& D = h->dec[l];
@@ -620,7 +631,7 @@ extern "C" int32_t amt_finalize(amt_handle* h) {
         // layer 0's in-projection of every table the decoder input is a sum of (video_music_transformer.py:984-1001,1029)
         const DecLayer& D0 = h->dec[0];
         const int d3 = 3 * (int)d;
-        if ((rc = amt_launch_gemm(gemm_params(h->PR, (int)d, D0.sa_w, (int)d, h->tab_r, d3, 15, d3, (int)d, nullptr), s))) return rc;
+        if ((rc = amt_launch_gemm(gemm_params(h->PR, (int)d, D0.sa_w, (int)d, h->tab_r, d3, h->n_root, d3, (int)d, nullptr), s))) return rc;
         if ((rc = amt_launch_gemm(gemm_params(h->PA, (int)d, D0.sa_w, (int)d, h->tab_a, d3, 16, d3, (int)d, nullptr), s))) return rc;
         if ((rc = amt_launch_gemm(gemm_params(h->wkey, (int)d, D0.sa_w, (int)d, h->tab_k, d3, 1, d3, (int)d, nullptr), s))) return rc;
         if ((rc = amt_launch_gemm(gemm_params(bc, (int)d, D0.sa_w, (int)d, h->tab_cb, d3, 1, d3, (int)d, nullptr), s))) return rc;
@@ -651,6 +662,27 @@ extern "C" int32_t amt_finalize(amt_handle* h) {
 // ------------------------------------------------------------------------------------------------
 // encoder
 // ------------------------------------------------------------------------------------------------
+extern "C" int32_t amt_set_option(amt_handle* h, const char* name, int32_t value) {
+    AMT_CHECK_ARG(h && name, "amt_set_option: null argument");
+    if (strcmp(name, "chord_embed") == 0) {
+        AMT_CHECK_ARG(!h->KVx || h->chord_embed == (value != 0), "amt_set_option: chord_embed must be chosen before the first amt_finalize");
+        h->chord_embed = value != 0;
+        return 0;
+    }
+    AMT_CHECK_ARG(false, "amt_set_option: unknown option '%s'", name);
+    return -1;
+}
+
+extern "C" int32_t amt_encode_resid(amt_handle* h, int32_t B, int32_t S, const float* sem, int32_t sem_dim, const float* scene,
+                                    const float* motion, int32_t motion_dim, const float* emotion, int32_t emo_dim,
+                                    const float* vis_resid, float* memory_out, void* stream) {
+    AMT_CHECK_ARG(h, "amt_encode_resid: null handle");
+    h->vis_resid = vis_resid;
+    const int32_t rc = amt_encode(h, B, S, sem, sem_dim, scene, motion, motion_dim, emotion, emo_dim, memory_out, stream);
+    h->vis_resid = nullptr;
+    return rc;
+}
+
 extern "C" int32_t amt_encode(amt_handle* h, int32_t B, int32_t S, const float* sem, int32_t sem_dim, const float* scene,
                               const float* motion, int32_t motion_dim, const float* emotion, int32_t emo_dim,
                               float* memory_out, void* stream) {
@@ -669,6 +701,7 @@ extern "C" int32_t amt_encode(amt_handle* h, int32_t B, int32_t S, const float* 
     {   // Linear_vis + positional encoding of the frame index
         GemmParams g = gemm_params(h->wsA0, h->Fpad, h->Wvis_pad, h->Fpad, h->wsX, d, R, d, h->Fpad, W(h, "Linear_vis.bias"));
         g.rowadd = h->pe_v; g.rowadd_period = S;
+        g.resid = h->vis_resid; g.ldr = d;               // scene_embed: + scene_embedding(feature_scene_offset.int()) (:1026-1027)
         if ((rc = amt_launch_gemm(g, s))) return rc;
     }
     for (int l = 0; l < h->nl; ++l) {

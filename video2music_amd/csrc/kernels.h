@@ -191,6 +191,7 @@ struct SampleParams {
     // ([.][3d] tables).  q (x q_scale) goes to q0 [B][d], k / v into layer 0's cache row of that position.
     const float* tab_r; const float* tab_a; const float* tab_k; const float* tab_p;
     float* q0; float* kc0; float* vc0; int H, hd, cap; float q_scale;
+    int chord_embed;                 // 1: the chosen chord id feeds back as the "root" index (table = chord embedding), attr = 0
 };
 int32_t amt_launch_sample(const SampleParams& p, hipStream_t stream);
 // writes x_next for position *pos from the token sequences (start of generate / external sampling)

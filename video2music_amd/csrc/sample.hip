@@ -21,6 +21,15 @@ constexpr int V = 159, VP = 157;       // CHORD_SIZE, CHORD_END
 constexpr int ROOT_PAD = 14, ATTR_PAD = 15;
 constexpr int NWS = 16;                 // waves of the sampling workgroup
 
+// (root, attr) the chosen token feeds back as the next input (model/video_music_transformer.py:1107-1123: chord.json's layout,
+// plain roots carry attr 1, N = (0, 1); beam == 1 leaves the PAD pair, :1078-1084).  chord_embed (:926-937, 986-987): the chord
+// id itself indexes the frozen table, in both branches; the attr slot indexes an all-zero row.
+__device__ __forceinline__ void feedback_of(const SampleParams& p, int tok, int& root, int& attr) {
+    if (p.chord_embed) { root = tok; attr = 0; }
+    else if (p.beam == 0) { root = tok == 0 ? 0 : (tok - 1) / 13 + 1; attr = tok == 0 ? 1 : (tok - 1) % 13 + 1; }
+    else { root = ROOT_PAD; attr = ATTR_PAD; }
+}
+
 __device__ __forceinline__ void write_next_input(const SampleParams& p, int b, int cur, int root, int attr) {
     const float kv = p.key[b];
     for (int c = threadIdx.x * 4; c < p.d; c += blockDim.x * 4) {
@@ -269,12 +278,7 @@ __global__ __launch_bounds__(NWS * 64) void sample_kernel(SampleParams p) {
             attr = (int)p.attrs[(size_t)b * p.T + cur];
         } else {
             tok = s_tok;
-            if (p.beam == 0) {
-                root = tok == 0 ? 0 : (tok - 1) / 13 + 1;
-                attr = tok == 0 ? 1 : (tok - 1) % 13 + 1;
-            } else {
-                root = ROOT_PAD; attr = ATTR_PAD;
-            }
+            feedback_of(p, tok, root, attr);
             if (tid == 0) {
                 p.tokens[(size_t)b * p.T + cur] = tok;
                 p.roots[(size_t)b * p.T + cur] = root;
@@ -396,12 +400,7 @@ __global__ __launch_bounds__(256) void sample_fold_kernel(SampleParams p) {
             attr = (int)p.attrs[(size_t)b * p.T + cur];
         } else {
             tok = s_tok;
-            if (p.beam == 0) {
-                root = tok == 0 ? 0 : (tok - 1) / 13 + 1;
-                attr = tok == 0 ? 1 : (tok - 1) % 13 + 1;
-            } else {
-                root = ROOT_PAD; attr = ATTR_PAD;
-            }
+            feedback_of(p, tok, root, attr);
             if (tid == 0) {
                 p.tokens[(size_t)b * p.T + cur] = tok;
                 p.roots[(size_t)b * p.T + cur] = root;
@@ -419,17 +418,17 @@ __global__ __launch_bounds__(256) void embed_step_kernel(SampleParams p, int adv
     const int b = blockIdx.x;
     const int t = *p.pos, cur = t + advance;
     if (cur < p.T) {
-        if (advance && p.beam == 0 && cur >= p.n_primer && threadIdx.x == 0) {
-            const int tok = (int)p.tokens[(size_t)b * p.T + cur];
-            p.roots[(size_t)b * p.T + cur] = tok == 0 ? 0 : (tok - 1) / 13 + 1;
-            p.attrs[(size_t)b * p.T + cur] = tok == 0 ? 1 : (tok - 1) % 13 + 1;
+        const bool fb = advance && (p.beam == 0 || p.chord_embed) && cur >= p.n_primer;
+        if (fb && threadIdx.x == 0) {
+            int r, a;
+            feedback_of(p, (int)p.tokens[(size_t)b * p.T + cur], r, a);
+            p.roots[(size_t)b * p.T + cur] = r;
+            p.attrs[(size_t)b * p.T + cur] = a;
         }
         __syncthreads();
         int root, attr;
-        if (advance && p.beam == 0 && cur >= p.n_primer) {
-            const int tok = (int)p.tokens[(size_t)b * p.T + cur];
-            root = tok == 0 ? 0 : (tok - 1) / 13 + 1;
-            attr = tok == 0 ? 1 : (tok - 1) % 13 + 1;
+        if (fb) {
+            feedback_of(p, (int)p.tokens[(size_t)b * p.T + cur], root, attr);
         } else {
             root = (int)p.roots[(size_t)b * p.T + cur];
             attr = (int)p.attrs[(size_t)b * p.T + cur];

@@ -120,8 +120,6 @@ class VideoMusicTransformer(nn.Module):
         # rpr=False (the class default; generate.py passes RPR=True) selects torch's stock decoder layers (:957-962): the same
         # layer without the relative-position table.  It runs on the same kernels with an all-zero Er (the bias q.Er is then
         # exactly 0), which is not part of the state_dict.
-        if scene_embed or chord_embed:
-            raise NotImplementedError("scene_embed / chord_embed are outside the hot path (SURVEY.md §2 row 28)")
         self.nlayers = n_layers
         self.nhead = num_heads
         self.d_model = d_model
@@ -135,6 +133,14 @@ class VideoMusicTransformer(nn.Module):
         self.chord_embed = chord_embed
         self.total_vf_dim = total_vf_dim
 
+        if scene_embed:                          # vf = Linear_vis(features without the scene column) + scene_embedding(offset) (:926-928,1016-1027)
+            self.scene_embedding = nn.Embedding(SCENE_OFFSET_MAX, d_model)
+        if chord_embed:
+            # the reference fills this from a gensim Word2Vec file (:931-935) that the tree does not ship; here the frozen table
+            # arrives with the state_dict (key chord_embedding_model.weight, any number of rows >= the ids fed, width d_model)
+            self.chord_embedding_model = nn.Embedding(CHORD_SIZE, d_model)
+            self.chord_embedding_model.weight.requires_grad_(False)
+            self._register_load_state_dict_pre_hook(self._resize_chord_table)
         self.embedding = nn.Embedding(CHORD_SIZE, d_model)
         self.embedding_root = nn.Embedding(CHORD_ROOT_SIZE, d_model)
         self.embedding_attr = nn.Embedding(CHORD_ATTR_SIZE, d_model)
@@ -162,14 +168,32 @@ class VideoMusicTransformer(nn.Module):
                                 "(`.to('cuda')`); video2music_amd has no CPU fallback")
         return dev
 
-    def _ensure_handle(self):
+    def _resize_chord_table(self, state_dict, prefix, *_):
+        w = state_dict.get(prefix + "chord_embedding_model.weight")
+        if w is not None and tuple(w.shape) != tuple(self.chord_embedding_model.weight.shape):
+            if w.dim() != 2 or w.shape[1] != self.d_model:
+                raise ValueError("chord_embedding_model.weight must be (n_chords, d_model)")
+            cur = self.chord_embedding_model.weight
+            self.chord_embedding_model.weight = nn.Parameter(torch.empty(w.shape, dtype=cur.dtype, device=cur.device), requires_grad=False)
+
+    def _ensure_handle(self, sem_dim=None):
         dev = self._device()
         torch.cuda.set_device(dev)
+        if self.scene_embed:
+            # the library keeps the scene column in its feature rows; its weight column is zero and the embedding rows enter as a
+            # residual of the Linear_vis product (amt_encode_resid).  The column sits right behind the semantic features.
+            if sem_dim is None:
+                sem_dim = getattr(self, "_scene_col", None)
+            assert sem_dim is not None, "scene_embed: the semantic feature width is known at the first forward / generate"
+            if getattr(self, "_scene_col", None) != sem_dim:
+                self._scene_col, self._weights_sig = sem_dim, None
         if self._handle is None:
             cfg = _lib.AmtConfig(self.nlayers, self.nhead, self.d_model, self.d_ff, self.max_seq_video,
-                                 self.max_seq_chord, self.total_vf_dim, MAX_DECODE_BATCH)
+                                 self.max_seq_chord, self.total_vf_dim + int(bool(self.scene_embed)), MAX_DECODE_BATCH)
             h = C.c_void_p()
             _lib.call("amt_create", C.byref(cfg), C.byref(h))
+            if self.chord_embed:
+                _lib.call("amt_set_option", h, b"chord_embed", 1)
             self._handle = h
             self._weights_sig = None
         sig = tuple((k, v.data_ptr(), v._version) for k, v in self.state_dict().items())
@@ -177,6 +201,14 @@ class VideoMusicTransformer(nn.Module):
             torch.cuda.synchronize(dev)
             for name, t in self.state_dict().items():
                 t = t.detach().to(torch.float32).contiguous()
+                if name == "Linear_vis.weight" and self.scene_embed:
+                    c = self._scene_col
+                    t = torch.cat([t[:, :c], torch.zeros(t.shape[0], 1, device=t.device), t[:, c:]], dim=1).contiguous()
+                if self.chord_embed:                 # the chord table takes the root table's place, the attr table is all zero
+                    if name == "embedding_root.weight":
+                        t = self.chord_embedding_model.weight.detach().to(torch.float32).contiguous()
+                    elif name == "embedding_attr.weight":
+                        t = torch.zeros_like(t)
                 shape = (C.c_int64 * t.dim())(*t.shape)
                 _lib.call("amt_load_weight", self._handle, name.encode(), _lib.ptr(t), t.dim(), shape)
             if not self.rpr:
@@ -223,9 +255,13 @@ class VideoMusicTransformer(nn.Module):
 
     def _encode(self, h, sem, scene, motion, emotion, sl, memory_out=None):
         B, S = sem[sl].shape[0], sem.shape[1]
-        _lib.call("amt_encode", h, B, S, _lib.ptr(sem[sl].contiguous()), sem.shape[2], _lib.ptr(scene[sl].contiguous()),
+        resid = None
+        if self.scene_embed:                        # + scene_embedding(feature_scene_offset.int()) (:1026-1027)
+            idx = scene[sl].to(torch.int32).long().reshape(-1)
+            resid = self.scene_embedding.weight.detach().to(torch.float32)[idx].contiguous()
+        _lib.call("amt_encode_resid", h, B, S, _lib.ptr(sem[sl].contiguous()), sem.shape[2], _lib.ptr(scene[sl].contiguous()),
                   _lib.ptr(motion[sl].contiguous()), motion.shape[2], _lib.ptr(emotion[sl].contiguous()), emotion.shape[2],
-                  _lib.ptr(memory_out), _lib.stream_ptr())
+                  _lib.ptr(resid), _lib.ptr(memory_out), _lib.stream_ptr())
 
     # ------------------------------------------------------------------------------------------
     # forward
@@ -239,12 +275,14 @@ class VideoMusicTransformer(nn.Module):
         if mask is not True:
             raise NotImplementedError("forward(mask=False) is not part of the hot path; every reference caller "
                                       "uses the causal mask (utilities/run_model_vevo.py:84-91)")
-        h = self._ensure_handle()
         dev = self._device()
         B, L = x.shape[0], x.shape[1]
         sem, key, scene, motion, emotion, Bf, S = self._prep_features(feature_semantic_list, feature_key,
                                                                      feature_scene_offset, feature_motion, feature_emotion)
+        h = self._ensure_handle(sem.shape[2])
         assert Bf == B, f"{B} chord sequences but {Bf} clips of video features"
+        if self.chord_embed:                     # x = chord_embedding_model(x) (:986-987): the ids index the table, the attr slot a zero row
+            x_root, x_attr = x, torch.zeros_like(x)
         roots = x_root.to(device=dev, dtype=torch.long).contiguous()
         attrs = x_attr.to(device=dev, dtype=torch.long).contiguous()
         logits = torch.empty(B, L, CHORD_SIZE, device=dev, dtype=torch.float32)
@@ -262,10 +300,10 @@ class VideoMusicTransformer(nn.Module):
     def forward_debug(self, x_root, x_attr, feature_semantic_list, feature_key, feature_scene_offset,
                       feature_motion, feature_emotion, layer_index=0):
         """(logits, encoder memory (B,S,d), output of decoder layer ``layer_index`` (B,L,d)) for parity tests."""
-        h = self._ensure_handle()
         dev = self._device()
         sem, key, scene, motion, emotion, B, S = self._prep_features(feature_semantic_list, feature_key,
                                                                     feature_scene_offset, feature_motion, feature_emotion)
+        h = self._ensure_handle(sem.shape[2])
         assert B <= MAX_DECODE_BATCH
         L = x_root.shape[1]
         memory = torch.empty(B, S, self.d_model, device=dev)
@@ -299,10 +337,10 @@ class VideoMusicTransformer(nn.Module):
         decode kernel launch (``amt_generate_profile``).  Returns ``(tokens, stats)`` where stats maps
         kernel class -> {"ms", "launches", "bytes"}; ``bytes`` = algorithmic fp32 K/V bytes."""
         assert (not self.training), "Cannot generate while in training mode"
-        h = self._ensure_handle()
         dev = self._device()
         sem, key, scene, motion, emotion, B, S = self._prep_features(feature_semantic_list, feature_key,
                                                                     feature_scene_offset, feature_motion, feature_emotion)
+        h = self._ensure_handle(sem.shape[2])
         assert B <= MAX_DECODE_BATCH
         T = int(target_seq_length)
         prim = [torch.as_tensor(p).to(device=dev, dtype=torch.long).contiguous() for p in (primer, primer_root, primer_attr)]
@@ -345,16 +383,19 @@ class VideoMusicTransformer(nn.Module):
             raise NotImplementedError("beam_chance < 1 mixes the two branches at random; not a parity target")
         if sampler not in ("categorical", "multinomial", "argmax"):
             raise ValueError(f"unknown sampler {sampler!r}")
-        h = self._ensure_handle()
         dev = self._device()
         sem, key, scene, motion, emotion, B, S = self._prep_features(feature_semantic_list, feature_key,
                                                                     feature_scene_offset, feature_motion, feature_emotion)
+        h = self._ensure_handle(sem.shape[2])
         T = int(target_seq_length)
         prim = [torch.as_tensor(p).to(device=dev, dtype=torch.long).contiguous() for p in (primer, primer_root, primer_attr)]
         per_clip = prim[0].dim() == 2
         P = prim[0].shape[-1]
         assert all(p.shape == prim[0].shape for p in prim), "primer / primer_root / primer_attr shapes differ"
         assert (not per_clip) or prim[0].shape[0] == B
+        if self.chord_embed:                     # the ids are the model input (:986-987), in both branches: no one-pass shortcut
+            prim[1], prim[2] = prim[0], torch.zeros_like(prim[0])
+            one_pass_top1 = False
         tokens = torch.empty(B, T, device=dev, dtype=torch.long)
         if beam == 1 and one_pass_top1 and not return_logits and T > P:
             roots = torch.full((B, T - 1), CHORD_ROOT_PAD, device=dev, dtype=torch.long)
