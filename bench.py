@@ -357,6 +357,10 @@ def main():
         torch.cuda.synchronize(device)
 
     with torch.no_grad():
+        if world > 1:
+            # setup, not a step: the first collective creates the RCCL communicator (hundreds of ms) — keep it out of the timed
+            # region even under --warmup 0
+            vdist.all_gather_sequences(torch.zeros(B, T, dtype=torch.long, device=device), world * B)
         for _ in range(args.warmup):
             step()
         barrier()
