@@ -86,14 +86,24 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
     const int kt0 = wave * tpw;
 
     // ---- 1. the row this wave stages: row m0+wave (clamped to the last valid row) ----
+    const int zg = p.n_groups > 1 ? (int)blockIdx.z : 0;     // grouped launch: one expert per blockIdx.z
     const int r = m0 + wave, rc = min(r, p.B - 1);
-    const float* xr = p.x + (size_t)rc * p.ldx;
+    const float* xr = p.x + (size_t)zg * p.x_group_off + (size_t)rc * p.ldx;
     const float* x2r = p.x2 ? p.x2 + (size_t)rc * p.ldx2 - K1 : xr;
     float4 v[KCH];
 #pragma unroll
     for (int c = 0; c < KCH; ++c) {
         const int i = (c * 64 + lane) * 4, ic = FULL ? i : min(i, K - 4);
         v[c] = ld4((ic < K1 ? xr : x2r) + ic);
+    }
+    float4 gv[PRO == 3 ? KCH : 1];
+    if (PRO == 3) {
+        const float* gr = p.glu_gate + (size_t)zg * p.x_group_off + (size_t)rc * p.ldx;
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            const int i = (c * 64 + lane) * 4, ic = FULL ? i : min(i, K - 4);
+            gv[c] = ld4(gr + ic);
+        }
     }
     // ---- 2. prologue vectors ----
     float4 g0[PRO == 1 ? KCH : 1], h0[PRO == 1 ? KCH : 1];
@@ -115,7 +125,7 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
     }
     // ---- 3. this wave's weight tiles (tile index clamped: surplus loads repeat the last tile) ----
     float4 wt[KCH];
-    const int grp = p.sel ? *p.sel : 0;             // device-chosen weight group (mixture-of-experts, one token)
+    const int grp = p.sel ? *p.sel : zg;            // device-chosen weight group (mixture-of-experts, one token) or the launch's group
     const float* wbase = high ? p.Wp2 + (size_t)(nt - nts) * kt_n * 256 : p.Wp + (size_t)grp * p.sel_w_stride + (size_t)nt * kt_n * 256;
     // un-packed weights (ldw > 0): lane (n = lane & 15, k-quad = lane >> 4) reads its float4 of row n directly: 16 rows x 64 B
     // per tile instead of one 1 KiB run, still one fully used 64-B segment per row
@@ -187,6 +197,14 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
             v[c].z = (v[c].z - mean) * rstd * g0[c].z + h0[c].z; v[c].w = (v[c].w - mean) * rstd * g0[c].w + h0[c].w;
         }
     }
+    if (PRO == 3) {
+        const float um = p.glu_only ? 0.f : 1.f, uo = p.glu_only ? 1.f : 0.f;      // h = u * silu(g), or silu(g) alone
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            v[c].x = (v[c].x * um + uo) * (gv[c].x / (1.0f + __expf(-gv[c].x))); v[c].y = (v[c].y * um + uo) * (gv[c].y / (1.0f + __expf(-gv[c].y)));
+            v[c].z = (v[c].z * um + uo) * (gv[c].z / (1.0f + __expf(-gv[c].z))); v[c].w = (v[c].w * um + uo) * (gv[c].w / (1.0f + __expf(-gv[c].w)));
+        }
+    }
 #pragma unroll
     for (int c = 0; c < KCH; ++c) {
         const int i = (c * 64 + lane) * 4;
@@ -199,7 +217,7 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
     // ---- 4. epilogue operands: issued behind the prologue so that no register of the prologue's arithmetic sits
     // next to a pending load (packed VALU ops read register pairs).  Absent operands read a zero word instead of
     // being masked after the load: a select on a loaded value would be scheduled early and wait for the weights ----
-    const float* bp = high ? p.bias2 : (p.bias ? p.bias + (size_t)grp * p.sel_b_stride : nullptr);
+    const float* bp = high ? p.bias2 : (p.bias ? p.bias + (size_t)grp * p.sel_b_stride : nullptr);      // (grp = blockIdx.z in a grouped launch)
     const bool has_b = live && bp != nullptr, has_r = PRO != 2 && live && !high && p.mode == 0 && p.resid != nullptr;
     const float e_bias = *(has_b ? bp + (high ? n - p.n_split : n) : p.zero);
     float e_res = 0.f;
@@ -240,11 +258,24 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
     for (int rr = 0; rr < 4; ++rr) rw[rr * 64 + lane] = acc[rr];
     __syncthreads();
     STAMP(5);
-    if (live) {
-        float val = 0.f;
+    float val = 0.f;
+    if (tid < 256) {
 #pragma unroll
         for (int w = 0; w < NW; ++w) val += red[w * 256 + tid];
         val += e_bias;
+    }
+    if (p.rope) {
+        // interleaved pairs sit in adjacent lanes of the same row (16-column tiles): even column y = x*c - x'*s, odd y = x*c + x'*s
+        const float other = __shfl_xor(val, 1, 64);
+        if (n < p.rope_cols) {
+            const int e2 = (n % p.rope_dim) & ~1;
+            const float* rp = p.rope + (size_t)t * p.rope_dim + e2;
+            const float c = rp[0], sn = rp[1];
+            val = (n & 1) ? val * c + other * sn : val * c - other * sn;
+        }
+    }
+    if (live) {
+        float* ybase = p.y + (size_t)zg * p.y_group_off;
         if (high) {
             p.y2[(size_t)row * p.ldy2 + (n - p.n_split)] = val;
         } else {
@@ -252,9 +283,9 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
             if (p.mode == 0) {
                 val += e_res;
                 if (p.relu) val = fmaxf(val, 0.f);
-                p.y[(size_t)row * p.ldy + n] = val;
+                ybase[(size_t)row * p.ldy + n] = val;
             } else if (n < p.d) {
-                p.y[(size_t)row * p.ldy + n] = val;
+                ybase[(size_t)row * p.ldy + n] = val;
             } else {
                 const int nn = (n < 2 * p.d) ? n - p.d : n - 2 * p.d;
                 const int hh = nn / p.hd, cc = nn - hh * p.hd;
@@ -288,7 +319,7 @@ int32_t launch_one(const DecodeGemmParams& p, size_t lds, hipStream_t stream) {
             attr_set[dev] = true;
         }
     }
-    hipLaunchKernelGGL((decode_gemm_kernel<KCH, FULL, PRO>), dim3(cdiv(p.N, 16), cdiv(p.B, MT)), dim3(NW * 64), lds, stream, p);
+    hipLaunchKernelGGL((decode_gemm_kernel<KCH, FULL, PRO>), dim3(cdiv(p.N, 16), cdiv(p.B, MT), p.n_groups > 1 ? p.n_groups : 1), dim3(NW * 64), lds, stream, p);
     AMT_LAUNCH_CHECK();
     return 0;
 }
@@ -296,6 +327,7 @@ int32_t launch_one(const DecodeGemmParams& p, size_t lds, hipStream_t stream) {
 template <int KCH, bool FULL>
 int32_t launch_variant(const DecodeGemmParams& p, size_t lds, hipStream_t stream) {
     if (p.pro == 1) return launch_one<KCH, FULL, 2>(p, lds, stream);
+    if (p.glu_gate) return launch_one<KCH, FULL, 3>(p, lds, stream);
     if (p.ln_w) { if constexpr (KCH <= 4) return launch_one<KCH, FULL, 1>(p, lds, stream); }
     return launch_one<KCH, FULL, 0>(p, lds, stream);
 }
@@ -342,6 +374,9 @@ int32_t amt_launch_decode_gemm(const DecodeGemmParams& p_in, hipStream_t stream)
                                  "decode_gemm: bad column split %d of N=%d", p.n_split, p.N);
     AMT_CHECK_ARG(!p.sel || p.n_split == 0, "decode_gemm: a device-selected weight group cannot be combined with a column split");
     AMT_CHECK_ARG(p.ldw == 0 || (p.ldw >= p.K && p.ldw % 4 == 0 && p.n_split == 0 && !p.sel), "decode_gemm: bad un-packed weight (ldw=%d)", p.ldw);
+    AMT_CHECK_ARG(p.n_groups <= 1 || (!p.sel && p.n_split == 0 && !p.x2 && p.ldw == 0 && !p.resid && p.mode == 0 && p.n_groups <= 65535), "decode_gemm: a grouped launch takes plain single-source products");
+    AMT_CHECK_ARG(!p.glu_gate || (!p.x2 && !p.ln_w && p.pro == 0), "decode_gemm: the gated prologue takes a single source and no LayerNorm");
+    AMT_CHECK_ARG(!p.rope || (p.pos && p.rope_dim > 0 && p.rope_dim % 2 == 0 && p.rope_cols % 2 == 0 && p.n_split == 0), "decode_gemm: bad rotary epilogue");
     if (p.pro == 1) AMT_CHECK_ARG(p.x2 && p.fold_g && p.fold_c && p.ln_w && p.ln_b && !p.resid, "decode_gemm: incomplete folded-FFN prologue");
     else AMT_CHECK_ARG(!p.ln_w || (!p.x2 && p.K <= 1024), "decode_gemm: the LayerNorm prologue takes a single source of K <= 1024");
     size_t lds = (size_t)MT * (p.K + XPAD) * sizeof(float);

@@ -123,6 +123,18 @@ struct DecodeGemmParams {
     // the packed weight of group *sel starts sel_w_stride floats further, its bias sel_b_stride floats further
     const int* sel; size_t sel_w_stride; int sel_b_stride;
     int ldw;                    // > 0: Wp is NOT packed but a plain nn.Linear weight [N][ldw] (small-M products of the dense paths)
+    // Grouped launch (n_groups > 1, blockIdx.z = group; Wp-only launches): group e reads its input rows at x + e*x_group_off
+    // (same ldx), its packed weight at Wp + e*sel_w_stride, its bias at bias + e*sel_b_stride, and writes y + e*y_group_off:
+    // the down-projections of all experts of a mixture layer in one launch
+    int n_groups; size_t x_group_off, y_group_off;
+    // Gated-linear-unit prologue (glu_gate != null; single source, no LayerNorm): the staged row is x * silu(glu_gate)
+    // (GLUExpert.forward, moe.py:44-49), or silu(glu_gate) alone when glu_only (the Linear -> SiLU -> Linear experts of V1);
+    // glu_gate has x's row stride and group offset
+    const float* glu_gate; int glu_only;
+    // Rotary epilogue (rope != null): columns n < rope_cols are rotated as interleaved pairs (2i, 2i+1) by the angles of
+    // position *pos in the table rope[pos][rope_dim] = (cos, sin) pairs (custom_transformer.py:1044-1053 as wired: the full
+    // d_model vector, pair i by angle i); applied after the bias and before `scale`.  Column n uses table entry n % rope_dim.
+    const float* rope; int rope_cols, rope_dim;
     const float* zero;          // set by the launcher: zero words in global memory
     // diagnostic builds only (-DAMT_STAMPS, tools/ubench_chain.cpp): [workgroup][8] s_memrealtime stamps (100 MHz) of the
     // kernel's phases; null and unused in the library build
@@ -131,6 +143,10 @@ struct DecodeGemmParams {
 int32_t amt_launch_decode_gemm(const DecodeGemmParams& p, hipStream_t stream);
 // allocates the per-device zero words (hipMalloc): call once outside any stream capture
 int32_t amt_decode_gemm_init();
+
+// mixture-of-experts combine with the layer's residual added (moe.hip): out = sum_e w_e Y[slot_e] (+ shared_scale * shared) + resid
+int32_t amt_launch_moe_combine(const float* y_rows, const int32_t* slot_pos, const int32_t* idx, const float* wts, const float* shared,
+                               float shared_scale, const float* resid, float* out, int n_tok, int d, hipStream_t stream);
 
 // ---------------- load-time LayerNorm folding (fold.hip) ----------------
 int32_t amt_launch_scale_cols(const float* W, const float* gamma, float* out, int N, int K, hipStream_t stream);   // out = W o gamma

@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void moe_place_kernel(const int* __restrict__ 
 
 __global__ void moe_combine_kernel(const float* __restrict__ Y, const int* __restrict__ slot_pos,
                                    const int* __restrict__ idx, const float* __restrict__ wts,
-                                   const float* __restrict__ shared, float shared_scale, float* __restrict__ out, int d) {
+                                   const float* __restrict__ shared, float shared_scale, float* __restrict__ out, int d,
+                                   const float* __restrict__ resid = nullptr) {
     const int tok = blockIdx.x;
     int a = 0, b = 1;
     if (idx[tok * 2] > idx[tok * 2 + 1]) { a = 1; b = 0; }        // accumulate in expert-index order (moe.py:191-199)
@@ -113,6 +114,10 @@ __global__ void moe_combine_kernel(const float* __restrict__ Y, const int* __res
         if (shared) {
             const float4 s = ld4(shared + (size_t)tok * d + c);
             o.x += shared_scale * s.x; o.y += shared_scale * s.y; o.z += shared_scale * s.z; o.w += shared_scale * s.w;
+        }
+        if (resid) {                           // the layer's residual: out = mixture(x) + x (the sum the following norm takes)
+            const float4 r = ld4(resid + (size_t)tok * d + c);
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
         st4(out + (size_t)tok * d + c, o);
     }
@@ -228,6 +233,13 @@ extern "C" int32_t amt_glu_expert_fwd(const float* x, const float* w1, const flo
         if ((rc = amt_launch_gemm(u, s))) return rc;
     }
     return amt_launch_gemm(gemm_params(Hh, dff, w2, dff, out, d, n, d, dff, b2), s);
+}
+
+int32_t amt_launch_moe_combine(const float* y_rows, const int32_t* slot_pos, const int32_t* idx, const float* wts, const float* shared,
+                               float shared_scale, const float* resid, float* out, int n_tok, int d, hipStream_t stream) {
+    hipLaunchKernelGGL(moe_combine_kernel, dim3(n_tok), dim3(128), 0, stream, y_rows, slot_pos, idx, wts, shared, shared_scale, out, d, resid);
+    AMT_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int32_t amt_moe_combine_fwd(const float* y_rows, const int32_t* slot_pos, const int32_t* idx, const float* wts,

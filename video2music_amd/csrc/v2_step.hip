@@ -316,8 +316,41 @@ int32_t glu_rows(const float* x, const float* w1, const float* b1, const float* 
 
 extern "C" int64_t amt_v2_step_batch_ws_floats(int32_t E, int32_t dff, int32_t n_exp, int32_t B) {
     const int64_t ne = n_exp > 0 ? n_exp : 1;
-    return (int64_t)B * ((int64_t)(9 + n_exp) * E + 3 * ne * dff + 8) + 64;
+    return (int64_t)B * ((int64_t)(12 + n_exp) * E + 3 * ne * dff + 8) + 64;
 }
+
+namespace {
+
+// One skinny-GEMM launch of the lockstep step with the fusions of round 2 (each replaces a separate launch):
+//   ln_w / ln_b : LayerNorm of the input rows in the prologue, the normalised rows also written to xn (needs N >= K)
+//   rope        : rotary epilogue on the first rope_cols output columns (position from device memory)
+//   qkv         : mode-1 epilogue -- q scaled to y, k / v rows of this position into the head-major caches
+//   gate        : gated-linear-unit prologue, input row = x * silu(gate) (or silu(gate) when x == null)
+//   groups      : one launch for the same product of `groups` experts
+struct RowGemm {
+    const float* x = nullptr; int ldx = 0; const float* wp = nullptr; const float* b = nullptr; const float* resid = nullptr;
+    float* y = nullptr; int N = 0, K = 0;
+    const float* ln_w = nullptr; const float* ln_b = nullptr; float* xn = nullptr;
+    const float* rope = nullptr; int rope_cols = 0, rope_dim = 0; const int* pos = nullptr; float scale = 1.f; int scale_cols = 0;
+    bool qkv = false; float* kc = nullptr; float* vc = nullptr; int H = 0, hd = 0, cap = 0;
+    const float* gate = nullptr; bool gate_only = false;
+    int groups = 1; size_t x_goff = 0, y_goff = 0, w_gstride = 0; int b_gstride = 0;
+};
+
+int32_t row_gemm(const RowGemm& r, int B, hipStream_t s) {
+    DecodeGemmParams g{};
+    g.B = B; g.eps = 1e-5f; g.scale = r.scale; g.scale_cols = r.scale_cols;
+    g.x = r.x ? r.x : r.gate; g.ldx = r.ldx ? r.ldx : r.K; g.Wp = r.wp; g.bias = r.b; g.N = r.N; g.K = r.K;
+    g.resid = r.resid; g.ldr = r.N; g.y = r.y; g.ldy = r.qkv ? r.N / 3 : r.N;
+    g.ln_w = r.ln_w; g.ln_b = r.ln_b; g.xn = r.xn;
+    g.rope = r.rope; g.rope_cols = r.rope_cols; g.rope_dim = r.rope_dim; g.pos = r.pos;
+    if (r.qkv) { g.mode = 1; g.kcache = r.kc; g.vcache = r.vc; g.H = r.H; g.hd = r.hd; g.cap = r.cap; g.d = r.N / 3; }
+    g.glu_gate = r.gate; g.glu_only = r.gate && !r.x;
+    g.n_groups = r.groups; g.x_group_off = r.x_goff; g.y_group_off = r.y_goff; g.sel_w_stride = r.w_gstride; g.sel_b_stride = r.b_gstride;
+    return amt_launch_decode_gemm(g, s);
+}
+
+}  // namespace
 
 extern "C" int32_t amt_v2_step_batch(const void* const* tab, int32_t n_layers, int32_t H, int32_t E, int32_t dff, int32_t n_exp,
                                      int32_t S, int32_t max_seq, int32_t B, const float* keys_dev, int32_t* state_dev,
@@ -333,7 +366,8 @@ extern "C" int32_t amt_v2_step_batch(const void* const* tab, int32_t n_layers, i
     const size_t BE = (size_t)B * E;
     float* x = ws; float* y = x + BE; float* qkv = y + BE; float* q = qkv + 3 * BE; float* o = q + BE; float* u = o + BE;
     float* ysh = u + BE;                                  // shared expert output [B][E]
-    float* Yall = ysh + BE;                               // every expert's output [n_exp][B][E]
+    float* xa = ysh + BE; float* xb = xa + BE; float* xc = xb + BE;      // LayerNorm outputs written by the fused prologues
+    float* Yall = xc + BE;                                // every expert's output [n_exp][B][E]
     float* ffs = Yall + (size_t)n_exp * BE;               // 3 * B * max(n_exp, 1) * dff expert scratch
     float* moe_w = ffs + (size_t)3 * B * (n_exp > 0 ? n_exp : 1) * dff;   // routing weights [B][2], indices [B][2], rows in Yall [B][2]
     int32_t* moe_idx = (int32_t*)(moe_w + 2 * B);
@@ -343,51 +377,101 @@ extern "C" int32_t amt_v2_step_batch(const void* const* tab, int32_t n_layers, i
     hipLaunchKernelGGL(embed_rows_kernel, dim3(B), dim3(128), 0, s, state_dev, B, keys_dev, G(G_PR), G(G_PA), G(G_WKEY), G(G_CBIAS), x, E, G(G_PE));
     AMT_LAUNCH_CHECK();
     const float* rope = G(G_ROPE);
+    // A LayerNorm that feeds a projection runs in that projection's prologue (E <= 1024; RMSNorm models keep their own launch).
+    // `cur` holds either finished rows (pend_w == null) or the pre-norm sum that the pending LayerNorm (pend_w, pend_b) completes.
+    const bool fuse_ln = E <= 1024;
+    float* cur = x;
+    const float *pend_w = nullptr, *pend_b = nullptr;
+    // finishes a pending norm into `dst` by its own launch (RMSNorm, or nothing to fuse it into)
+    auto settle = [&](float* dst) -> int32_t {
+        if (!pend_w) return 0;
+        int32_t r2 = norm_rows(cur, nullptr, pend_w, pend_b, dst, B, E, s);
+        cur = dst; pend_w = pend_b = nullptr;
+        return r2;
+    };
     for (int l = 0; l < n_layers; ++l) {
         const void* const* L = tab + G_PTRS + (size_t)l * L_PTRS;
         auto P = [&](int i) { return (const float*)L[i]; };
         float* kc = (float*)L[L_KC]; float* vc = (float*)L[L_VC];                 // [B][H][max_seq][hd]
-        if ((rc = lin_rows(x, P(L_SAW), P(L_SAB), nullptr, qkv, B, 3 * E, E, s))) return rc;
-        hipLaunchKernelGGL(place_qkv_rows_kernel, dim3(cdiv(E / 2, 256), B, 3), dim3(256), 0, s, qkv, rope, q, kc, vc, qscale, E, hd, max_seq, pos);
-        AMT_LAUNCH_CHECK();
+        // ---- self-attention: [pending LayerNorm ->] QKV projection -> rotary -> q / cache rows, one launch ----
+        if (pend_w && !(fuse_ln && pend_b)) { if ((rc = settle(xa))) return rc; }
+        {
+            RowGemm r; r.x = cur; r.wp = P(L_SAW); r.b = P(L_SAB); r.y = q; r.N = 3 * E; r.K = E;
+            if (pend_w) { r.ln_w = pend_w; r.ln_b = pend_b; r.xn = xa; }
+            r.rope = rope; r.rope_cols = 2 * E; r.rope_dim = E; r.pos = pos; r.scale = qscale; r.scale_cols = E;
+            r.qkv = true; r.kc = kc; r.vc = vc; r.H = H; r.hd = hd; r.cap = max_seq;
+            if ((rc = row_gemm(r, B, s))) return rc;
+            if (pend_w) { cur = xa; pend_w = pend_b = nullptr; }
+        }
         if ((rc = attn_rows(q, kc, vc, o, B, H, hd, max_seq, 0, pos, s))) return rc;
-        if ((rc = lin_rows(o, P(L_SAOW), P(L_SAOB), x, u, B, E, E, s))) return rc;
-        if ((rc = norm_rows(u, nullptr, P(L_N1W), P(L_N1B), x, B, E, s))) return rc;
-        if ((rc = lin_rows(x, P(L_CAW), P(L_CAB), nullptr, qkv, B, E, E, s))) return rc;
-        if ((rc = place_rows(qkv, E, rope, q, qscale, B, E, hd, 0, pos, 0, s))) return rc;
+        if ((rc = lin_rows(o, P(L_SAOW), P(L_SAOB), cur, u, B, E, E, s))) return rc;           // u = out-proj + residual
+        cur = u; pend_w = P(L_N1W); pend_b = P(L_N1B);
+        // ---- cross-attention: [norm1 ->] query projection -> rotary, scale ----
+        if (!(fuse_ln && pend_b)) { if ((rc = settle(xb))) return rc; }
+        {
+            RowGemm r; r.x = cur; r.wp = P(L_CAW); r.b = P(L_CAB); r.y = q; r.N = E; r.K = E;
+            if (pend_w) { r.ln_w = pend_w; r.ln_b = pend_b; r.xn = xb; }
+            r.rope = rope; r.rope_cols = E; r.rope_dim = E; r.pos = pos; r.scale = qscale; r.scale_cols = E;
+            if ((rc = row_gemm(r, B, s))) return rc;
+            if (pend_w) { cur = xb; pend_w = pend_b = nullptr; }
+        }
         if ((rc = attn_rows(q, P(L_KX), P(L_VX), o, B, H, hd, S, S, nullptr, s))) return rc;      // [B][H][S][hd]
-        if ((rc = lin_rows(o, P(L_CAOW), P(L_CAOB), x, u, B, E, E, s))) return rc;
-        if ((rc = norm_rows(u, nullptr, P(L_N2W), P(L_N2B), x, B, E, s))) return rc;
+        if ((rc = lin_rows(o, P(L_CAOW), P(L_CAOB), cur, y, B, E, E, s))) return rc;
+        cur = y; pend_w = P(L_N2W); pend_b = P(L_N2B);
+        // ---- feed-forward: [norm2 ->] gate projection; up projection; down projection with the gate applied in its prologue ----
+        if (!(fuse_ln && pend_b)) { if ((rc = settle(xc))) return rc; }
+        const float* ffin;                                   // the normalised rows every projection of the block reads
         if (!L[L_GATEW]) {
-            if ((rc = glu_rows(x, P(L_W1), P(L_B1), P(L_WG), P(L_BG), P(L_W2), P(L_B2), y, ffs, B, E, dff, s))) return rc;
+            float* gate = ffs; float* up = gate + (size_t)B * dff;
+            RowGemm rg; rg.x = cur; rg.wp = P(L_WG); rg.b = P(L_BG); rg.y = gate; rg.N = dff; rg.K = E;
+            if (pend_w) { rg.ln_w = pend_w; rg.ln_b = pend_b; rg.xn = xc; }
+            if ((rc = row_gemm(rg, B, s))) return rc;
+            if (pend_w) { cur = xc; pend_w = pend_b = nullptr; }
+            ffin = cur;
+            if (P(L_W1) && (rc = lin_rows(ffin, P(L_W1), P(L_B1), nullptr, up, B, dff, E, s))) return rc;
+            RowGemm rd; rd.x = P(L_W1) ? up : nullptr; rd.gate = gate; rd.wp = P(L_W2); rd.b = P(L_B2); rd.resid = ffin; rd.y = u; rd.N = E; rd.K = dff;
+            if ((rc = row_gemm(rd, B, s))) return rc;             // u = expert(x) + x : the pre-norm sum of norm3
         } else {
-            if ((rc = amt_moe_route_fwd(x, P(L_GATEW), P(L_GATEB), moe_idx, moe_w, B, E, n_exp, s))) return rc;
             // gate and up projections of ALL experts in one launch each: the experts' packed weights lie one after the other,
             // which is the packed form of the stacked (n_exp*dff, E) matrix (tiles of 16 output rows, dff % 16 == 0)
             const int Nall = n_exp * dff;
-            float* Gall = ffs; float* Uall = Gall + (size_t)B * Nall; float* Hall = Uall + (size_t)B * Nall;
-            if ((rc = lin_rows(x, P(L_WG), P(L_BG), nullptr, Gall, B, Nall, E, s))) return rc;
-            if (P(L_W1) && (rc = lin_rows(x, P(L_W1), P(L_B1), nullptr, Uall, B, Nall, E, s))) return rc;
-            hipLaunchKernelGGL(glu_mul_kernel, dim3(cdiv(B * Nall, 1024)), dim3(256), 0, s, P(L_W1) ? Uall : nullptr, Gall, Hall, B * Nall);
-            AMT_LAUNCH_CHECK();
-            const size_t pw2 = (size_t)E * dff;                                                  // packed linear2 per expert
-            for (int e = 0; e < n_exp; ++e)
-                if ((rc = lin_rows(Hall + (size_t)e * dff, P(L_W2) + e * pw2, P(L_B2) + (size_t)e * E, nullptr, Yall + e * BE, B, E, dff, s, Nall)))
-                    return rc;
+            float* Gall = ffs; float* Uall = Gall + (size_t)B * Nall;
+            RowGemm rg; rg.x = cur; rg.wp = P(L_WG); rg.b = P(L_BG); rg.y = Gall; rg.N = Nall; rg.K = E;
+            if (pend_w) { rg.ln_w = pend_w; rg.ln_b = pend_b; rg.xn = xc; }
+            if ((rc = row_gemm(rg, B, s))) return rc;
+            if (pend_w) { cur = xc; pend_w = pend_b = nullptr; }
+            ffin = cur;
+            if ((rc = amt_moe_route_fwd(ffin, P(L_GATEW), P(L_GATEB), moe_idx, moe_w, B, E, n_exp, s))) return rc;
+            if (P(L_W1) && (rc = lin_rows(ffin, P(L_W1), P(L_B1), nullptr, Uall, B, Nall, E, s))) return rc;
+            // the down projections of all experts in ONE grouped launch (blockIdx.z = expert), gate applied in the prologue
+            RowGemm rd; rd.x = P(L_W1) ? Uall : nullptr; rd.gate = Gall; rd.ldx = Nall; rd.wp = P(L_W2); rd.b = P(L_B2); rd.y = Yall; rd.N = E; rd.K = dff;
+            rd.groups = n_exp; rd.x_goff = (size_t)dff; rd.y_goff = BE; rd.w_gstride = (size_t)E * dff; rd.b_gstride = E;
+            if ((rc = row_gemm(rd, B, s))) return rc;
             hipLaunchKernelGGL(dense_slot_kernel, dim3(cdiv(2 * B, 256)), dim3(256), 0, s, moe_idx, slot_pos, B);
             AMT_LAUNCH_CHECK();
             const float* shared = nullptr;
             if (L[L_SWG]) {
-                if ((rc = glu_rows(x, P(L_SW1), P(L_SB1), P(L_SWG), P(L_SBG), P(L_SW2), P(L_SB2), ysh, ffs, B, E, dff, s))) return rc;
+                float* sg = Gall + (size_t)2 * B * Nall; float* su = sg + (size_t)B * dff;          // third slab of the expert scratch
+                if ((rc = lin_rows(ffin, P(L_SWG), P(L_SBG), nullptr, sg, B, dff, E, s))) return rc;
+                if (P(L_SW1) && (rc = lin_rows(ffin, P(L_SW1), P(L_SB1), nullptr, su, B, dff, E, s))) return rc;
+                RowGemm rs; rs.x = P(L_SW1) ? su : nullptr; rs.gate = sg; rs.wp = P(L_SW2); rs.b = P(L_SB2); rs.y = ysh; rs.N = E; rs.K = dff;
+                if ((rc = row_gemm(rs, B, s))) return rc;
                 shared = ysh;
             }
-            if ((rc = amt_moe_combine_fwd(Yall, slot_pos, moe_idx, moe_w, shared, 0.5f, y, B, E, s))) return rc;
+            if ((rc = amt_launch_moe_combine(Yall, slot_pos, moe_idx, moe_w, shared, 0.5f, ffin, u, B, E, s))) return rc;     // + residual
         }
-        if ((rc = norm_rows(y, x, P(L_N3W), P(L_N3B), u, B, E, s))) return rc;
-        float* tmp = x; x = u; u = tmp;
+        cur = u; pend_w = P(L_N3W); pend_b = P(L_N3B);
+        // (the next layer's QKV launch consumes `u` before that layer's out-projection writes it again)
+        if (l + 1 < n_layers && !(fuse_ln && pend_b)) { if ((rc = settle(x))) return rc; }
     }
-    if ((rc = norm_rows(x, nullptr, G(G_FNW), G(G_FNB), y, B, E, s))) return rc;
-    if ((rc = lin_rows(y, G(G_WOUT), G(G_BOUT), nullptr, logits_out, B, 159, E, s))) return rc;
+    if ((rc = settle(x))) return rc;                                     // norm3 of the last layer
+    if (fuse_ln && G(G_FNB)) {                                            // decoder.norm in the prologue of the output head
+        RowGemm r; r.x = cur; r.wp = G(G_WOUT); r.b = G(G_BOUT); r.y = logits_out; r.N = 159; r.K = E; r.ln_w = G(G_FNW); r.ln_b = G(G_FNB);
+        if ((rc = row_gemm(r, B, s))) return rc;
+    } else {
+        if ((rc = norm_rows(cur, nullptr, G(G_FNW), G(G_FNB), y, B, E, s))) return rc;
+        if ((rc = lin_rows(y, G(G_WOUT), G(G_BOUT), nullptr, logits_out, B, 159, E, s))) return rc;
+    }
     hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, s, state_dev);
     AMT_LAUNCH_CHECK();
     return 0;
