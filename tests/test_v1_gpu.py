@@ -125,3 +125,7 @@ def test_lockstep_generate_batch_equals_per_clip_generate(make, B, P):
         assert torch.equal(a, m.generate_batch(*args, pr[0][0], pr[1][0], pr[2][0], target_seq_length=T, beam=0, uniforms=u))
         lo = m.generate_batch(*args, pr[0][0], pr[1][0], pr[2][0], target_seq_length=T, beam=0, uniforms=torch.zeros(T, B))
         assert set(lo[:, P + 1:].flatten().tolist()) <= {1, 2}
+        # one clip through the lockstep step (B = 1, decision on the device) equals the one-call step with the host decision
+        one = [a[:1] for a in args]
+        assert torch.equal(m.generate_batch(*one, pr[0][0], pr[1][0], pr[2][0], target_seq_length=T, beam=0, sampler="argmax"),
+                           m.generate_batch(*one, pr[0][0], pr[1][0], pr[2][0], target_seq_length=T, beam=0, sampler="argmax", decision="host"))

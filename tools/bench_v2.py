@@ -22,7 +22,7 @@ with torch.no_grad():
     for _ in range(3): m(root, root, attr, f8["semantic"], f8["key"], f8["scene_offset"], f8["motion"], f8["emotion"])
     torch.cuda.synchronize(); df = (time.perf_counter() - t0) / 3
     batch = {}
-    for nb in (4, 16, 32):                   # lockstep generate_batch: clips per second and per-step time
+    for nb in (1, 4, 16, 32):                   # lockstep generate_batch: clips per second and per-step time
         fb = {k: torch.from_numpy(v).cuda() for k, v in synthetic.synthetic_features(nb, seed=5).items()}
         args = (fb["semantic"], fb["key"], fb["scene_offset"], fb["motion"], fb["emotion"], kw["primer"], kw["primer_root"], kw["primer_attr"])
         m.generate_batch(*args, target_seq_length=8, beam=0, sampler="argmax")

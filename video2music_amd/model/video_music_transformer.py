@@ -833,8 +833,9 @@ class VideoMusicTransformer_V2(nn.Module):
         # amt_v2_step lays its scratch out for one feed-forward width; layers of different widths (V1 '1.3.3' / '1.3.4' with
         # dim_feedforward != 2 d_model) take the same cached step issued operator by operator (`_decode_step`)
         st["native"] = len(widths) == 1
-        n_ws = (_lib.call("amt_v2_step_ws_floats", E, dff, self.n_experts) if nb == 1
-                else _lib.call("amt_v2_step_batch_ws_floats", E, dff, self.n_experts, nb))
+        # (one clip may run either step: the one-call step with device-routed experts or the lockstep step with B = 1)
+        n_ws = max(_lib.call("amt_v2_step_ws_floats", E, dff, self.n_experts) if nb == 1 else 0,
+                   _lib.call("amt_v2_step_batch_ws_floats", E, dff, self.n_experts, nb))
         st["ws"] = torch.empty(n_ws, device=dev, dtype=torch.float32)
         st["logits"] = torch.empty(CHORD_SIZE, device=dev, dtype=torch.float32) if nb == 1 else torch.empty(nb, CHORD_SIZE, device=dev)
         return st
@@ -955,15 +956,15 @@ class VideoMusicTransformer_V2(nn.Module):
         rows, _, S = self._encode_memory(feature_semantic_list, feature_scene_offset, feature_motion, feature_emotion, clips=True)
         mems = [rows[c * S:(c + 1) * S] for c in range(nb)]
         st = self._cache_init(mems, S)
-        if nb == 1 or not st["native"]:            # one clip, or layers of unequal width: the single-clip loop
+        if decision not in ("device", "host"):
+            raise ValueError(f"unknown decision {decision!r}")
+        if (nb == 1 and decision == "host") or not st["native"]:      # layers of unequal width, or the host loop for one clip
             rows = [self.generate(feature_semantic_list[c:c + 1], key[c], feature_scene_offset[c:c + 1], feature_motion[c:c + 1],
                                   feature_emotion[c:c + 1], prim[0][c], prim[1][c], prim[2][c], target_seq_length=T, beam=beam,
                                   beam_chance=beam_chance, max_conseq_N=max_conseq_N, max_conseq_chord=max_conseq_chord,
                                   temperature=temperature, sampler=sampler, use_graph=use_graph) for c in range(nb)]
             return torch.cat(rows)
         keys = key.to(dev)
-        if decision not in ("device", "host"):
-            raise ValueError(f"unknown decision {decision!r}")
         if decision == "device":
             return self._lockstep_device(st, keys, gen, gen_root, gen_attr, nb, T, P, beam, max_conseq_N, max_conseq_chord,
                                          temperature, sampler, use_graph, uniforms)
