@@ -162,13 +162,15 @@ def _sha256(path):
         return hashlib.sha256(fh.read()).hexdigest()
 
 
-def pmc_traffic(kind, algorithmic_bytes_per_launch):
+def pmc_traffic(kind, algorithmic_bytes_per_launch, shape_ok=True):
     """HBM bytes per launch of the decode attention from the committed PMC pass (FETCH_SIZE doubled per the gfx950 correction +
     WRITE_SIZE, collected by tools/pmc_attn.py under rocprofv3 --pmc in separate passes) scaled to this run's algorithmic bytes.
     Counters cannot be read from inside bench.py, so the figure is only reported while the kernel source is byte-identical to
     the one the pass was collected on (sha256 recorded in the profile); otherwise null."""
     path = os.path.join(ROOT, "profiles", "r02_pmc_attn_traffic.json")
     src = os.path.join(ROOT, "video2music_amd", "csrc", "attn_decode.hip")
+    if not shape_ok:
+        return None, "the committed PMC pass was collected at config 2's launch shape (B=32, H=8, hd=64) only"
     if not (os.path.exists(path) and os.path.exists(src)):
         return None, "no committed PMC pass"
     prof = json.load(open(path))
@@ -263,7 +265,8 @@ def roofline(model, f, prim, B, T, cfg):
     n_gemm = st["decode_gemm"]["launches"] / steps
     sample_us = max(raw_us("sample") - empty_us, 0.0)
     gemm_in_chain_us = (step_us - nl * (self_us + cross_us) - sample_us) / max(n_gemm, 1)
-    traffic, traffic_src = pmc_traffic("self_attn", self_bytes)
+    shape_ok = B == 32 and d == 512 and cfg["num_heads"] == 8
+    traffic, traffic_src = pmc_traffic("self_attn", self_bytes, shape_ok)
     return {
         "bound": "hbm", "kernel": "attn_decode_kernel<64, true, true, {0,2}> (relative-position self-attention, decode step; FOLD 2 in layers 1-5)",
         "achieved": round(self_bytes / self_us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -277,7 +280,7 @@ def roofline(model, f, prim, B, T, cfg):
         "cross_attn": {"kernel": "attn_decode_kernel<64, false, true, 1> (cross-attention over video K/V, decode step)",
                        "algorithmic_bytes_per_launch": round(cross_bytes), "avg_launch_us": round(cross_us, 3),
                        "achieved": round(cross_bytes / cross_us / 1e3, 1), "frac": round(cross_bytes / cross_us / 1e3 / HBM_PEAK_GBS, 4),
-                       "traffic": pmc_traffic("cross_attn", cross_bytes)[0], "event_pair": ev("cross_attn_decode", cross_bytes)},
+                       "traffic": pmc_traffic("cross_attn", cross_bytes, shape_ok)[0], "event_pair": ev("cross_attn_decode", cross_bytes)},
         "decode_gemm": {"kernel": "decode_gemm_kernel<4,true,0> (G1, G2) and <6,true,2> (G3): weight-streaming skinny GEMMs, 18 launches per step",
                         "packed_weight_bytes_per_launch": round(gemm_bytes), "avg_launch_us": round(gemm_in_chain_us, 3),
                         "achieved": round(gemm_bytes / gemm_in_chain_us / 1e3, 1), "frac": round(gemm_bytes / gemm_in_chain_us / 1e3 / HBM_PEAK_GBS, 4),
