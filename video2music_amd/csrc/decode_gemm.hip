@@ -165,15 +165,24 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
 #pragma unroll
         for (int c = 0; c < KCH; ++c) {
             const int i = (c * 64 + lane) * 4;
-            // one branch-free form for both halves (x*1.0f is exact): raw half a = mu*g, m = 1, relu; LN half a = mu, m = g
             const int ic = FULL ? i : min(i, K - 4);
             const float4 g = ld4(gs + ic), h = ld4(gs + K + ic);
-            const bool rawh = i < K1;
-            const float lo = rawh ? 0.f : -INFINITY;
-            v[c].x = fmaxf((v[c].x - (rawh ? mean * g.x : mean)) * rstd * (rawh ? 1.f : g.x) + h.x, lo);
-            v[c].y = fmaxf((v[c].y - (rawh ? mean * g.y : mean)) * rstd * (rawh ? 1.f : g.y) + h.y, lo);
-            v[c].z = fmaxf((v[c].z - (rawh ? mean * g.z : mean)) * rstd * (rawh ? 1.f : g.z) + h.z, lo);
-            v[c].w = fmaxf((v[c].w - (rawh ? mean * g.w : mean)) * rstd * (rawh ? 1.f : g.w) + h.w, lo);
+            // a 256-column chunk lies on one side of K1 in every shape the model builds (K1 = dim_feedforward, a multiple of 256
+            // at config 2; 256 at config 1): the side is then wave-uniform and each half takes its own short formula
+            if (256 * c + 256 <= K1) {               // raw half: relu((raw - mu*g)*rstd + c)
+                v[c].x = fmaxf((v[c].x - mean * g.x) * rstd + h.x, 0.f); v[c].y = fmaxf((v[c].y - mean * g.y) * rstd + h.y, 0.f);
+                v[c].z = fmaxf((v[c].z - mean * g.z) * rstd + h.z, 0.f); v[c].w = fmaxf((v[c].w - mean * g.w) * rstd + h.w, 0.f);
+            } else if (256 * c >= K1) {              // LayerNorm half: (u - mu)*rstd*gamma + beta
+                v[c].x = (v[c].x - mean) * rstd * g.x + h.x; v[c].y = (v[c].y - mean) * rstd * g.y + h.y;
+                v[c].z = (v[c].z - mean) * rstd * g.z + h.z; v[c].w = (v[c].w - mean) * rstd * g.w + h.w;
+            } else {                                 // K1 inside the chunk: one branch-free form for both (x*1.0f is exact)
+                const bool rawh = i < K1;
+                const float lo = rawh ? 0.f : -INFINITY;
+                v[c].x = fmaxf((v[c].x - (rawh ? mean * g.x : mean)) * rstd * (rawh ? 1.f : g.x) + h.x, lo);
+                v[c].y = fmaxf((v[c].y - (rawh ? mean * g.y : mean)) * rstd * (rawh ? 1.f : g.y) + h.y, lo);
+                v[c].z = fmaxf((v[c].z - (rawh ? mean * g.z : mean)) * rstd * (rawh ? 1.f : g.z) + h.z, lo);
+                v[c].w = fmaxf((v[c].w - (rawh ? mean * g.w : mean)) * rstd * (rawh ? 1.f : g.w) + h.w, lo);
+            }
         }
     } else if (PRO == 1) {
         const float inv_k = 1.0f / (float)K;
