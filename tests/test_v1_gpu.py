@@ -109,7 +109,7 @@ def test_lockstep_generate_batch_equals_per_clip_generate(make, B, P):
             assert got.shape == (B, T)
             for c in range(B):
                 one = m.generate(f["semantic"][c:c + 1], f["key"][c], f["scene_offset"][c:c + 1], f["motion"][c:c + 1], f["emotion"][c:c + 1],
-                                 pr[0][c], pr[1][c], pr[2][c], target_seq_length=T, **kw)
+                                 pr[0][c], pr[1][c], pr[2][c], target_seq_length=T, decision="host", **kw)
                 assert torch.equal(one[0], got[c]), (kw, c)
         dev_ids = m.generate_batch(*args, *pr, target_seq_length=T, beam=0, sampler="argmax")
         eager = m.generate_batch(*args, *pr, target_seq_length=T, beam=0, sampler="argmax", use_graph=False)

@@ -45,6 +45,9 @@ def test_v2_generate_vs_reference_golden(golden, v2):
     with torch.no_grad():
         assert np.array_equal(m.generate(beam=1, **kw).cpu().numpy(), g["g1"])
         assert np.array_equal(m.generate(beam=0, sampler="argmax", **kw).cpu().numpy(), g["g2"])
+        # the round-1 loop (one-call step with device-routed experts, decision on the host) stays available
+        assert np.array_equal(m.generate(beam=1, decision="host", **kw).cpu().numpy(), g["g1"])
+        assert np.array_equal(m.generate(beam=0, sampler="argmax", decision="host", **kw).cpu().numpy(), g["g2"])
 
 
 def test_v2_longer_sequence_vs_oracle(v2):

@@ -962,7 +962,7 @@ class VideoMusicTransformer_V2(nn.Module):
             rows = [self.generate(feature_semantic_list[c:c + 1], key[c], feature_scene_offset[c:c + 1], feature_motion[c:c + 1],
                                   feature_emotion[c:c + 1], prim[0][c], prim[1][c], prim[2][c], target_seq_length=T, beam=beam,
                                   beam_chance=beam_chance, max_conseq_N=max_conseq_N, max_conseq_chord=max_conseq_chord,
-                                  temperature=temperature, sampler=sampler, use_graph=use_graph) for c in range(nb)]
+                                  temperature=temperature, sampler=sampler, use_graph=use_graph, decision="host") for c in range(nb)]
             return torch.cat(rows)
         keys = key.to(dev)
         if decision == "device":
@@ -1066,18 +1066,29 @@ class VideoMusicTransformer_V2(nn.Module):
     def generate(self, feature_semantic_list=[], feature_key=None, feature_scene_offset=None, feature_motion=None,
                  feature_emotion=None, primer=None, primer_root=None, primer_attr=None, target_seq_length=300, beam=0,
                  beam_chance=1.0, max_conseq_N=0, max_conseq_chord=2, temperature=1.0, sampler="categorical", use_cache=True,
-                 use_graph=True):
-        """Reference loop (:518-609) for one clip; the decision runs on the host like the reference's python loop
-        (softmax[:157] / temperature, N and repeat suppression, Categorical sample or arg-max).  The reference
-        re-runs the whole model every step; here the encoder runs once and the decoder one token at a time over
-        cached K/V (`use_cache=False` keeps the per-step re-forward of the decoder stack; `use_graph=False` issues the cached
-        step eagerly instead of replaying a captured graph — required when several host threads generate concurrently,
-        stream capture does not tolerate the other threads' synchronisations)."""
+                 use_graph=True, decision="device"):
+        """Reference loop (:518-609) for one clip.  The reference re-runs the whole model every step; here the encoder runs
+        once and the decoder one token at a time over cached K/V.
+
+        ``decision="device"`` (default, needs `use_cache` and `use_graph`): the clip takes the lockstep step with B = 1 and the
+        per-step decision of the reference loop runs inside the captured graph (`generate_batch`): no host round trip per token.
+        ``decision="host"``: the round-1 loop — the one-call step with device-routed experts, the decision on the host like
+        the reference's python loop (softmax[:157] / temperature, N and repeat suppression, torch's Categorical or arg-max);
+        `use_cache=False` keeps the per-step re-forward of the decoder stack; `use_graph=False` issues the cached step eagerly
+        instead of replaying a captured graph — required when several host threads generate concurrently (stream capture
+        does not tolerate the other threads' synchronisations)."""
         from ..utilities.constants import chord_to_root_attr
         assert (not self.training), "Cannot generate while in training mode"
         if beam not in (0, 1):
             raise NotImplementedError("beam > 1 is not implemented (generate.py:347-349 asserts it out as well)")
         print("Generating sequence of max length:", target_seq_length)
+        if decision not in ("device", "host"):
+            raise ValueError(f"unknown decision {decision!r}")
+        if decision == "device" and use_cache and use_graph and sampler in ("categorical", "argmax"):
+            return self.generate_batch(feature_semantic_list, feature_key, feature_scene_offset, feature_motion, feature_emotion,
+                                       primer, primer_root, primer_attr, target_seq_length=target_seq_length, beam=beam,
+                                       beam_chance=beam_chance, max_conseq_N=max_conseq_N, max_conseq_chord=max_conseq_chord,
+                                       temperature=temperature, sampler=sampler, use_graph=True, decision="device")
         dev = self.Wout.weight.device
         T = int(target_seq_length)
         gen = torch.full((1, T), CHORD_PAD, dtype=torch.long)
