@@ -144,9 +144,10 @@ int32_t amt_launch_decode_gemm(const DecodeGemmParams& p, hipStream_t stream);
 // allocates the per-device zero words (hipMalloc): call once outside any stream capture
 int32_t amt_decode_gemm_init();
 
-// mixture-of-experts combine with the layer's residual added (moe.hip): out = sum_e w_e Y[slot_e] (+ shared_scale * shared) + resid
+// mixture-of-experts combine with the layer's residual added (moe.hip): out = sum_e w_e Y[slot_e] (+ shared_scale * shared) + resid;
+// dense_B > 0: Y holds every expert's output for every token ([expert][dense_B][d]), slot_pos is not read
 int32_t amt_launch_moe_combine(const float* y_rows, const int32_t* slot_pos, const int32_t* idx, const float* wts, const float* shared,
-                               float shared_scale, const float* resid, float* out, int n_tok, int d, hipStream_t stream);
+                               float shared_scale, const float* resid, float* out, int n_tok, int d, hipStream_t stream, int dense_B = 0);
 
 // ---------------- load-time LayerNorm folding (fold.hip) ----------------
 int32_t amt_launch_scale_cols(const float* W, const float* gamma, float* out, int N, int K, hipStream_t stream);   // out = W o gamma

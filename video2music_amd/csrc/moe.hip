@@ -100,13 +100,14 @@ __global__ __launch_bounds__(256) void moe_place_kernel(const int* __restrict__ 
 __global__ void moe_combine_kernel(const float* __restrict__ Y, const int* __restrict__ slot_pos,
                                    const int* __restrict__ idx, const float* __restrict__ wts,
                                    const float* __restrict__ shared, float shared_scale, float* __restrict__ out, int d,
-                                   const float* __restrict__ resid = nullptr) {
+                                   const float* __restrict__ resid = nullptr, int dense_B = 0) {
     const int tok = blockIdx.x;
     int a = 0, b = 1;
     if (idx[tok * 2] > idx[tok * 2 + 1]) { a = 1; b = 0; }        // accumulate in expert-index order (moe.py:191-199)
     const float wa = wts[tok * 2 + a], wb = wts[tok * 2 + b];
-    const float* ya = Y + (size_t)slot_pos[tok * 2 + a] * d;
-    const float* yb = Y + (size_t)slot_pos[tok * 2 + b] * d;
+    // dense_B > 0: Y is [expert][dense_B tokens][d] (every expert evaluated on every token): the row follows from the expert id
+    const float* ya = Y + (size_t)(dense_B > 0 ? idx[tok * 2 + a] * dense_B + tok : slot_pos[tok * 2 + a]) * d;
+    const float* yb = Y + (size_t)(dense_B > 0 ? idx[tok * 2 + b] * dense_B + tok : slot_pos[tok * 2 + b]) * d;
     for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
         const float4 p = ld4(ya + c), q = ld4(yb + c);
         float4 o;
@@ -236,8 +237,8 @@ extern "C" int32_t amt_glu_expert_fwd(const float* x, const float* w1, const flo
 }
 
 int32_t amt_launch_moe_combine(const float* y_rows, const int32_t* slot_pos, const int32_t* idx, const float* wts, const float* shared,
-                               float shared_scale, const float* resid, float* out, int n_tok, int d, hipStream_t stream) {
-    hipLaunchKernelGGL(moe_combine_kernel, dim3(n_tok), dim3(128), 0, stream, y_rows, slot_pos, idx, wts, shared, shared_scale, out, d, resid);
+                               float shared_scale, const float* resid, float* out, int n_tok, int d, hipStream_t stream, int dense_B) {
+    hipLaunchKernelGGL(moe_combine_kernel, dim3(n_tok), dim3(128), 0, stream, y_rows, slot_pos, idx, wts, shared, shared_scale, out, d, resid, dense_B);
     AMT_LAUNCH_CHECK();
     return 0;
 }

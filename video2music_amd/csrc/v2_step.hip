@@ -16,10 +16,13 @@
 
 namespace {
 
-constexpr int G_PTRS = 11, L_PTRS = 32;
+constexpr int G_PTRS = 11, L_PTRS = 36;
 enum { G_PR, G_PA, G_WKEY, G_CBIAS, G_ROPE, G_FNW, G_FNB, G_WOUT, G_BOUT, G_SLOT01, G_PE };
 enum { L_SAW, L_SAB, L_SAOW, L_SAOB, L_N1W, L_N1B, L_CAW, L_CAB, L_CAOW, L_CAOB, L_N2W, L_N2B, L_N3W, L_N3B,
-       L_KC, L_VC, L_KX, L_VX, L_GATEW, L_GATEB, L_W1, L_B1, L_WG, L_BG, L_W2, L_B2, L_SW1, L_SB1, L_SWG, L_SBG, L_SW2, L_SB2 };
+       L_KC, L_VC, L_KX, L_VX, L_GATEW, L_GATEB, L_W1, L_B1, L_WG, L_BG, L_W2, L_B2, L_SW1, L_SB1, L_SWG, L_SBG, L_SW2, L_SB2,
+       // stacked forms for the lockstep step: [gate of every expert (+ shared) | linear1 of every expert (+ shared)] as ONE packed
+       // matrix and its bias; linear2 of every expert (+ shared) one after the other and their biases (null for a plain GLU layer)
+       L_GU, L_GUB, L_W2S, L_B2S };
 
 // (root, attr) either as launch arguments or, for a captured step graph, from device memory (tok[0], tok[1])
 __global__ void embed_one_kernel(int root, int attr, const int* __restrict__ tok, float kv, const float* __restrict__ PR,
@@ -267,12 +270,6 @@ __global__ void place_qkv_rows_kernel(const float* __restrict__ qkv, const float
     o[1] = y1 * scale;
 }
 
-// row of expert e's output for clip b inside Y[n_exp][B][E]
-__global__ void dense_slot_kernel(const int* __restrict__ idx, int* __restrict__ slot_pos, int B) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 2 * B) slot_pos[i] = idx[i] * B + (i >> 1);
-}
-
 int32_t lin_rows(const float* x, const float* wp, const float* b, const float* resid, float* y, int B, int N, int K, hipStream_t s,
                  int ldx = 0) {
     DecodeGemmParams g{};
@@ -300,23 +297,11 @@ int32_t attn_rows(const float* q, const float* k, const float* v, float* o, int 
     return amt_launch_attn_decode(a, s);
 }
 
-// expert on B rows; scratch 3*B*dff floats
-int32_t glu_rows(const float* x, const float* w1, const float* b1, const float* wg, const float* bg, const float* w2, const float* b2,
-                 float* y, float* scratch, int B, int E, int dff, hipStream_t s) {
-    float* g = scratch; float* u = g + (size_t)B * dff; float* hh = u + (size_t)B * dff;
-    int32_t rc;
-    if ((rc = lin_rows(x, wg, bg, nullptr, g, B, dff, E, s))) return rc;
-    if (w1 && (rc = lin_rows(x, w1, b1, nullptr, u, B, dff, E, s))) return rc;
-    hipLaunchKernelGGL(glu_mul_kernel, dim3(cdiv(B * dff, 1024)), dim3(256), 0, s, w1 ? u : nullptr, g, hh, B * dff);
-    AMT_LAUNCH_CHECK();
-    return lin_rows(hh, w2, b2, nullptr, y, B, E, dff, s);
-}
-
 }  // namespace
 
 extern "C" int64_t amt_v2_step_batch_ws_floats(int32_t E, int32_t dff, int32_t n_exp, int32_t B) {
     const int64_t ne = n_exp > 0 ? n_exp : 1;
-    return (int64_t)B * ((int64_t)(12 + n_exp) * E + 3 * ne * dff + 8) + 64;
+    return (int64_t)B * ((int64_t)(13 + n_exp) * E + 3 * (ne + 1) * dff + 8) + 64;
 }
 
 namespace {
@@ -368,10 +353,9 @@ extern "C" int32_t amt_v2_step_batch(const void* const* tab, int32_t n_layers, i
     float* ysh = u + BE;                                  // shared expert output [B][E]
     float* xa = ysh + BE; float* xb = xa + BE; float* xc = xb + BE;      // LayerNorm outputs written by the fused prologues
     float* Yall = xc + BE;                                // every expert's output [n_exp][B][E]
-    float* ffs = Yall + (size_t)n_exp * BE;               // 3 * B * max(n_exp, 1) * dff expert scratch
-    float* moe_w = ffs + (size_t)3 * B * (n_exp > 0 ? n_exp : 1) * dff;   // routing weights [B][2], indices [B][2], rows in Yall [B][2]
+    float* ffs = Yall + (size_t)(n_exp + 1) * BE;         // 3 * B * (max(n_exp, 1) + 1) * dff expert scratch (gate | up of every expert + shared)
+    float* moe_w = ffs + (size_t)3 * B * ((n_exp > 0 ? n_exp : 1) + 1) * dff;   // routing weights [B][2], indices [B][2]
     int32_t* moe_idx = (int32_t*)(moe_w + 2 * B);
-    int32_t* slot_pos = moe_idx + 2 * B;
     const int* pos = state_dev;
     int32_t rc;
     hipLaunchKernelGGL(embed_rows_kernel, dim3(B), dim3(128), 0, s, state_dev, B, keys_dev, G(G_PR), G(G_PA), G(G_WKEY), G(G_CBIAS), x, E, G(G_PE));
@@ -420,45 +404,33 @@ extern "C" int32_t amt_v2_step_batch(const void* const* tab, int32_t n_layers, i
         cur = y; pend_w = P(L_N2W); pend_b = P(L_N2B);
         // ---- feed-forward: [norm2 ->] gate projection; up projection; down projection with the gate applied in its prologue ----
         if (!(fuse_ln && pend_b)) { if ((rc = settle(xc))) return rc; }
+        // gate and up projections of the block are ONE product over the stacked matrix [gate | linear1] (of every expert and the
+        // shared one in a mixture layer: their packed weights lie one after the other, which is the packed form of the stacked
+        // matrix), with norm2 in its prologue; the down projection(s) apply u * silu(g) in their prologue
         const float* ffin;                                   // the normalised rows every projection of the block reads
-        if (!L[L_GATEW]) {
-            float* gate = ffs; float* up = gate + (size_t)B * dff;
-            RowGemm rg; rg.x = cur; rg.wp = P(L_WG); rg.b = P(L_BG); rg.y = gate; rg.N = dff; rg.K = E;
+        const bool has_up = P(L_W1) != nullptr;
+        const int ng = L[L_GATEW] ? n_exp + (L[L_SWG] ? 1 : 0) : 1;
+        const int Nall = ng * dff, Ngu = has_up ? 2 * Nall : Nall;
+        float* GU = ffs;                                     // [B][Ngu]: gate columns, then up columns
+        {
+            RowGemm rg; rg.x = cur; rg.wp = P(L_GU); rg.b = P(L_GUB); rg.y = GU; rg.N = Ngu; rg.K = E;
             if (pend_w) { rg.ln_w = pend_w; rg.ln_b = pend_b; rg.xn = xc; }
             if ((rc = row_gemm(rg, B, s))) return rc;
             if (pend_w) { cur = xc; pend_w = pend_b = nullptr; }
             ffin = cur;
-            if (P(L_W1) && (rc = lin_rows(ffin, P(L_W1), P(L_B1), nullptr, up, B, dff, E, s))) return rc;
-            RowGemm rd; rd.x = P(L_W1) ? up : nullptr; rd.gate = gate; rd.wp = P(L_W2); rd.b = P(L_B2); rd.resid = ffin; rd.y = u; rd.N = E; rd.K = dff;
+        }
+        if (!L[L_GATEW]) {
+            RowGemm rd; rd.x = has_up ? GU + Nall : nullptr; rd.gate = GU; rd.ldx = Ngu; rd.wp = P(L_W2); rd.b = P(L_B2); rd.resid = ffin;
+            rd.y = u; rd.N = E; rd.K = dff;
             if ((rc = row_gemm(rd, B, s))) return rc;             // u = expert(x) + x : the pre-norm sum of norm3
         } else {
-            // gate and up projections of ALL experts in one launch each: the experts' packed weights lie one after the other,
-            // which is the packed form of the stacked (n_exp*dff, E) matrix (tiles of 16 output rows, dff % 16 == 0)
-            const int Nall = n_exp * dff;
-            float* Gall = ffs; float* Uall = Gall + (size_t)B * Nall;
-            RowGemm rg; rg.x = cur; rg.wp = P(L_WG); rg.b = P(L_BG); rg.y = Gall; rg.N = Nall; rg.K = E;
-            if (pend_w) { rg.ln_w = pend_w; rg.ln_b = pend_b; rg.xn = xc; }
-            if ((rc = row_gemm(rg, B, s))) return rc;
-            if (pend_w) { cur = xc; pend_w = pend_b = nullptr; }
-            ffin = cur;
             if ((rc = amt_moe_route_fwd(ffin, P(L_GATEW), P(L_GATEB), moe_idx, moe_w, B, E, n_exp, s))) return rc;
-            if (P(L_W1) && (rc = lin_rows(ffin, P(L_W1), P(L_B1), nullptr, Uall, B, Nall, E, s))) return rc;
-            // the down projections of all experts in ONE grouped launch (blockIdx.z = expert), gate applied in the prologue
-            RowGemm rd; rd.x = P(L_W1) ? Uall : nullptr; rd.gate = Gall; rd.ldx = Nall; rd.wp = P(L_W2); rd.b = P(L_B2); rd.y = Yall; rd.N = E; rd.K = dff;
-            rd.groups = n_exp; rd.x_goff = (size_t)dff; rd.y_goff = BE; rd.w_gstride = (size_t)E * dff; rd.b_gstride = E;
+            // the down projections of all experts and the shared one in ONE grouped launch (blockIdx.z = expert)
+            RowGemm rd; rd.x = has_up ? GU + Nall : nullptr; rd.gate = GU; rd.ldx = Ngu; rd.wp = P(L_W2S); rd.b = P(L_B2S); rd.y = Yall; rd.N = E; rd.K = dff;
+            rd.groups = ng; rd.x_goff = (size_t)dff; rd.y_goff = BE; rd.w_gstride = (size_t)E * dff; rd.b_gstride = E;
             if ((rc = row_gemm(rd, B, s))) return rc;
-            hipLaunchKernelGGL(dense_slot_kernel, dim3(cdiv(2 * B, 256)), dim3(256), 0, s, moe_idx, slot_pos, B);
-            AMT_LAUNCH_CHECK();
-            const float* shared = nullptr;
-            if (L[L_SWG]) {
-                float* sg = Gall + (size_t)2 * B * Nall; float* su = sg + (size_t)B * dff;          // third slab of the expert scratch
-                if ((rc = lin_rows(ffin, P(L_SWG), P(L_SBG), nullptr, sg, B, dff, E, s))) return rc;
-                if (P(L_SW1) && (rc = lin_rows(ffin, P(L_SW1), P(L_SB1), nullptr, su, B, dff, E, s))) return rc;
-                RowGemm rs; rs.x = P(L_SW1) ? su : nullptr; rs.gate = sg; rs.wp = P(L_SW2); rs.b = P(L_SB2); rs.y = ysh; rs.N = E; rs.K = dff;
-                if ((rc = row_gemm(rs, B, s))) return rc;
-                shared = ysh;
-            }
-            if ((rc = amt_launch_moe_combine(Yall, slot_pos, moe_idx, moe_w, shared, 0.5f, ffin, u, B, E, s))) return rc;     // + residual
+            const float* shared = L[L_SWG] ? Yall + (size_t)n_exp * BE : nullptr;
+            if ((rc = amt_launch_moe_combine(Yall, nullptr, moe_idx, moe_w, shared, 0.5f, ffin, u, B, E, s, B))) return rc;     // + residual
         }
         cur = u; pend_w = P(L_N3W); pend_b = P(L_N3B);
         // (the next layer's QKV launch consumes `u` before that layer's out-projection writes it again)

@@ -803,12 +803,33 @@ class VideoMusicTransformer_V2(nn.Module):
                       nbias(lyr.norm2), lyr.norm3.weight, nbias(lyr.norm3), kc, vc, kx, vx):
                 add(t)
             ff = lyr.ff
+
+            def stacked(mods, with_down):
+                """[gate of every module | linear1 of every module] as ONE packed matrix + bias (the lockstep step's single
+                gate/up product), and, for a mixture layer, linear2 of every module one after the other + biases."""
+                parts = [expert_parts(e) for e in mods]
+                srcs = [q[n] for n in ("gate", "linear1", "linear2") for q in parts if q[n] is not None]
+                sig = tuple((l.weight.data_ptr(), l.weight._version, l.bias.data_ptr(), l.bias._version) for l in srcs) + ("stacked", with_down)
+                cache = self.__dict__.setdefault("_pack_cache", {})
+                if sig not in cache:
+                    gu = [q["gate"] for q in parts] + [q["linear1"] for q in parts if q["linear1"] is not None]
+                    out = [torch.cat([packed(l.weight) for l in gu]), torch.cat([l.bias.detach() for l in gu]).contiguous()]
+                    if with_down:
+                        out += [torch.cat([packed(q["linear2"].weight) for q in parts]),
+                                torch.cat([q["linear2"].bias.detach() for q in parts]).contiguous()]
+                    else:
+                        out += [None, None]
+                    cache[sig] = out
+                return cache[sig]
+
             if isinstance(ff, (GLUExpert, SiLUExpert)):
                 layer_dff = expert_dff(ff)
                 add(None), add(None)
                 add_expert(ff)
                 for _ in range(6):
                     add(None)
+                for t in stacked([ff], False):
+                    add(t)
             else:
                 if ff.n_experts_per_token != 2 or getattr(ff, "expert_parallel", False):
                     raise NotImplementedError("the cached V2 step is built for local top-2 MoE layers")
@@ -825,6 +846,8 @@ class VideoMusicTransformer_V2(nn.Module):
                 else:
                     for _ in range(6):
                         add(None)
+                for t in stacked(list(ff.experts) + ([ff.shared_expert] if ff.shared else []), True):
+                    add(t)
             widths.add(layer_dff)
             dff = layer_dff
         st["tab"] = (C.c_void_p * len(ptrs))(*ptrs)
