@@ -906,7 +906,7 @@ namespace {
 __global__ void commit_tokens_kernel(int64_t* tokens, const int64_t* chosen, const int* pos, int T, int n_primer) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     const int cur = *pos + 1;
-    if (b < gridDim.x * blockDim.x && cur < T && cur >= n_primer) tokens[(size_t)b * T + cur] = chosen[b];
+    if (b < (int)(gridDim.x * blockDim.x) && cur < T && cur >= n_primer) tokens[(size_t)b * T + cur] = chosen[b];
 }
 }  // namespace
 
