@@ -45,7 +45,7 @@ typedef struct amt_config {
     int32_t max_sequence_video;  /* 300: rows of positional_encoding_video.pe, key capacity of cross-attention */
     int32_t max_sequence_chord;  /* rows of Er / positional_encoding.pe = longest chord sequence */
     int32_t total_vf_dim;        /* width of the concatenated video feature (generate.py:141-160) */
-    int32_t max_batch;           /* clips per call (<= 32 per decode batch) */
+    int32_t max_batch;           /* clips per call, 1..256: sizes the K/V caches and workspaces (32 = BASELINE.json's per-GPU batch) */
 } amt_config;
 
 const char* amt_last_error(void);

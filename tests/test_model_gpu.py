@@ -547,3 +547,23 @@ def test_base_model_chord_embed_scene_embed_vs_reference_golden(golden, tag):
     toks = m.generate_batch(f3["semantic"], f3["key"], f3["scene_offset"], f3["motion"], f3["emotion"], torch.tensor([1]), torch.tensor([1]),
                             torch.tensor([0]), target_seq_length=32, beam=0, sampler="argmax")
     assert np.array_equal(toks[0].cpu().numpy(), g[f"{tag}_g2"][0])
+
+
+def test_more_than_32_clips_in_one_decode_chain():
+    """`model.max_decode_batch` (default 32, the per-GPU batch of BASELINE.json) sizes the handle: with 48, forty clips decode as ONE
+    lockstep chain (three 16-row blocks in the skinny GEMMs, 160 attention workgroups) and give the ids of the sliced default."""
+    feats = synthetic.synthetic_features(40, seed=61)
+    pr, prr, pra = (torch.tensor([v]) for v in C.primer_from_name("C"))
+    outs = []
+    for mdb in (32, 48):
+        m, _ = build(CFG1, seed=6)
+        m.max_decode_batch = mdb
+        f = cu(feats_t(feats))
+        toks, lg = m.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], pr, prr, pra,
+                                    target_seq_length=24, beam=0, sampler="argmax", return_logits=True)
+        outs.append((toks.cpu(), lg.cpu()))
+        root = torch.randint(0, 13, (40, 7), generator=torch.Generator().manual_seed(1))
+        with torch.no_grad():
+            outs[-1] += (m(root, root.cuda(), root.cuda(), f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"]).cpu(),)
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert (outs[0][1] - outs[1][1]).abs().max().item() < 1e-5 and (outs[0][2] - outs[1][2]).abs().max().item() < 1e-5

@@ -435,7 +435,7 @@ extern "C" int32_t amt_create(const amt_config* c, amt_handle** out) {
     AMT_CHECK_ARG(hd == 32 || hd == 64 || hd == 128, "amt_create: head_dim %d not in {32,64,128}", hd);
     AMT_CHECK_ARG(c->d_model % 64 == 0 && c->d_model <= 1024, "amt_create: d_model must be a multiple of 64 and <= 1024");
     AMT_CHECK_ARG(c->dim_feedforward % 64 == 0 && c->dim_feedforward <= 1536, "amt_create: dim_feedforward must be a multiple of 64 and <= 1536");
-    AMT_CHECK_ARG(c->max_batch > 0 && c->max_batch <= 32, "amt_create: max_batch must be in 1..32 (shard larger batches)");
+    AMT_CHECK_ARG(c->max_batch > 0 && c->max_batch <= 256, "amt_create: max_batch must be in 1..256 (shard larger batches)");
     AMT_CHECK_ARG(c->max_sequence_video > 0 && c->max_sequence_chord > 0 && c->total_vf_dim > 0, "amt_create: bad sequence dims");
     amt_handle* h = new amt_handle();
     h->cfg = *c;
@@ -559,7 +559,8 @@ extern "C" int32_t amt_finalize(amt_handle* h) {
         if ((rc = dev_alloc(h, &h->wkey, (size_t)d))) return rc;
         if ((rc = dev_alloc(h, &h->PR, (size_t)h->n_root * d))) return rc;
         if ((rc = dev_alloc(h, &h->PA, (size_t)16 * d))) return rc;
-        const size_t bd = (size_t)32 * d;
+        const size_t mb = (size_t)cdiv(h->maxB, 16) * 16;       // decode rows: whole 16-row blocks of the skinny GEMM
+        const size_t bd = mb * d;
         if ((rc = dev_alloc(h, &h->x_in, bd))) return rc;
         if ((rc = dev_alloc(h, &h->u1, bd))) return rc;
         if ((rc = dev_alloc(h, &h->u2, bd))) return rc;
@@ -569,13 +570,13 @@ extern "C" int32_t amt_finalize(amt_handle* h) {
         if ((rc = dev_alloc(h, &h->xc, bd))) return rc;
         if ((rc = dev_alloc(h, &h->qb, bd))) return rc;
         if ((rc = dev_alloc(h, &h->ob, bd))) return rc;
-        if ((rc = dev_alloc(h, &h->hb, (size_t)32 * dff))) return rc;
+        if ((rc = dev_alloc(h, &h->hb, mb * dff))) return rc;
         // folded chain: K = 2d and dff + d must fit the skinny GEMM, d the attention prologue
         const char* chain = getenv("AMT_DECODE_CHAIN");
         h->fold = !(chain && strcmp(chain, "plain") == 0) && d % 32 == 0 && d <= 1024 && (dff + d) % 64 == 0 && dff + d <= 1536 && dff % 16 == 0;
         if (h->fold) {
             if ((rc = dev_alloc(h, &h->qraw, bd))) return rc;
-            if ((rc = dev_alloc(h, &h->hraw, (size_t)32 * dff))) return rc;
+            if ((rc = dev_alloc(h, &h->hraw, mb * dff))) return rc;
             if ((rc = dev_alloc(h, &h->qkvraw, 3 * bd))) return rc;
             const size_t nmax = (size_t)std::max(3 * d, dff), kmax = (size_t)std::max(d, dff);
             if ((rc = dev_alloc(h, &h->tWs, nmax * d))) return rc;
@@ -584,14 +585,14 @@ extern "C" int32_t amt_finalize(amt_handle* h) {
             if ((rc = dev_alloc(h, &h->tComb, nmax * (kmax + d)))) return rc;
             if ((rc = dev_alloc(h, &h->tWs2, (size_t)VS * d))) return rc;
             if ((rc = dev_alloc(h, &h->vs, (size_t)6 * VS))) return rc;
-            if ((rc = dev_alloc(h, &h->lraw, (size_t)32 * VS))) return rc;
+            if ((rc = dev_alloc(h, &h->lraw, mb * VS))) return rc;
             if ((rc = dev_alloc(h, &h->tab_r, (size_t)h->n_root * 3 * d))) return rc;
             if ((rc = dev_alloc(h, &h->tab_a, (size_t)16 * 3 * d))) return rc;
             if ((rc = dev_alloc(h, &h->tab_k, (size_t)3 * d))) return rc;
             if ((rc = dev_alloc(h, &h->tab_cb, (size_t)3 * d))) return rc;
             if ((rc = dev_alloc(h, &h->tab_p, (size_t)h->Tcap * 3 * d))) return rc;
         }
-        if ((rc = dev_alloc(h, &h->keyb, (size_t)32))) return rc;
+        if ((rc = dev_alloc(h, &h->keyb, mb))) return rc;
         if ((rc = dev_alloc(h, &h->pos, (size_t)4))) return rc;
         if ((rc = dev_alloc(h, &h->ticket, (size_t)4))) return rc;
         if ((rc = dev_alloc(h, &h->unif, (size_t)h->maxB * h->Tcap))) return rc;

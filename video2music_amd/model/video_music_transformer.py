@@ -30,7 +30,7 @@ from ..utilities.constants import (CHORD_ATTR_PAD, CHORD_ATTR_SIZE, CHORD_END, C
                                    CHORD_ROOT_SIZE, CHORD_SIZE, IS_SEPERATED, SCENE_OFFSET_MAX)
 
 _CAPTURE_LOCK = threading.Lock()
-MAX_DECODE_BATCH = 32          # clips per library call; larger batches are processed in slices
+MAX_DECODE_BATCH = 32          # default clips per library call (`model.max_decode_batch`, up to 256); larger batches are processed in slices
 
 
 class PositionalEncoding(nn.Module):
@@ -157,6 +157,9 @@ class VideoMusicTransformer(nn.Module):
 
         self._handle = None
         self._weights_sig = None
+        # clips per library call (= per captured decode chain).  The K/V caches and workspaces of the handle are sized for it
+        # (config 2: ~2 GB at 32, ~8 GB at 128), so it must be set before the first forward / generate; larger batches are sliced.
+        self.max_decode_batch = MAX_DECODE_BATCH
 
     # ------------------------------------------------------------------------------------------
     # library handle / weight upload
@@ -189,7 +192,7 @@ class VideoMusicTransformer(nn.Module):
                 self._scene_col, self._weights_sig = sem_dim, None
         if self._handle is None:
             cfg = _lib.AmtConfig(self.nlayers, self.nhead, self.d_model, self.d_ff, self.max_seq_video,
-                                 self.max_seq_chord, self.total_vf_dim + int(bool(self.scene_embed)), MAX_DECODE_BATCH)
+                                 self.max_seq_chord, self.total_vf_dim + int(bool(self.scene_embed)), int(self.max_decode_batch))
             h = C.c_void_p()
             _lib.call("amt_create", C.byref(cfg), C.byref(h))
             if self.chord_embed:
@@ -286,8 +289,8 @@ class VideoMusicTransformer(nn.Module):
         roots = x_root.to(device=dev, dtype=torch.long).contiguous()
         attrs = x_attr.to(device=dev, dtype=torch.long).contiguous()
         logits = torch.empty(B, L, CHORD_SIZE, device=dev, dtype=torch.float32)
-        for b0 in range(0, B, MAX_DECODE_BATCH):
-            sl = slice(b0, min(B, b0 + MAX_DECODE_BATCH))
+        for b0 in range(0, B, self.max_decode_batch):
+            sl = slice(b0, min(B, b0 + self.max_decode_batch))
             nb = sl.stop - sl.start
             self._encode(h, sem, scene, motion, emotion, sl)
             out = logits[sl]
@@ -304,7 +307,7 @@ class VideoMusicTransformer(nn.Module):
         sem, key, scene, motion, emotion, B, S = self._prep_features(feature_semantic_list, feature_key,
                                                                     feature_scene_offset, feature_motion, feature_emotion)
         h = self._ensure_handle(sem.shape[2])
-        assert B <= MAX_DECODE_BATCH
+        assert B <= self.max_decode_batch
         L = x_root.shape[1]
         memory = torch.empty(B, S, self.d_model, device=dev)
         layer = torch.empty(B, L, self.d_model, device=dev)
@@ -341,7 +344,7 @@ class VideoMusicTransformer(nn.Module):
         sem, key, scene, motion, emotion, B, S = self._prep_features(feature_semantic_list, feature_key,
                                                                     feature_scene_offset, feature_motion, feature_emotion)
         h = self._ensure_handle(sem.shape[2])
-        assert B <= MAX_DECODE_BATCH
+        assert B <= self.max_decode_batch
         T = int(target_seq_length)
         prim = [torch.as_tensor(p).to(device=dev, dtype=torch.long).contiguous() for p in (primer, primer_root, primer_attr)]
         per_clip = prim[0].dim() == 2
@@ -402,8 +405,8 @@ class VideoMusicTransformer(nn.Module):
             attrs = torch.full((B, T - 1), CHORD_ATTR_PAD, device=dev, dtype=torch.long)
             roots[:, :P], attrs[:, :P] = prim[1], prim[2]
             lg = torch.empty(B, T - 1, CHORD_SIZE, device=dev, dtype=torch.float32)
-            for b0 in range(0, B, MAX_DECODE_BATCH):
-                sl = slice(b0, min(B, b0 + MAX_DECODE_BATCH))
+            for b0 in range(0, B, self.max_decode_batch):
+                sl = slice(b0, min(B, b0 + self.max_decode_batch))
                 self._encode(h, sem, scene, motion, emotion, sl)
                 _lib.call("amt_prefill", h, sl.stop - sl.start, T - 1, _lib.ptr(roots[sl].contiguous()), _lib.ptr(attrs[sl].contiguous()),
                           _lib.ptr(key[sl].contiguous()), _lib.ptr(lg[sl]), None, -1, _lib.stream_ptr())
@@ -411,8 +414,8 @@ class VideoMusicTransformer(nn.Module):
             tokens[:, P:] = lg[:, P - 1:, :CHORD_END].argmax(dim=-1)          # top-1 of softmax(...)[:157] (:1070-1084)
             return tokens
         logits = torch.zeros(T, B, CHORD_SIZE, device=dev) if return_logits else None
-        for b0 in range(0, B, MAX_DECODE_BATCH):
-            sl = slice(b0, min(B, b0 + MAX_DECODE_BATCH))
+        for b0 in range(0, B, self.max_decode_batch):
+            sl = slice(b0, min(B, b0 + self.max_decode_batch))
             nb = sl.stop - sl.start
             self._encode(h, sem, scene, motion, emotion, sl)
             pr = [p[sl].contiguous() if per_clip else p for p in prim]
