@@ -18,8 +18,8 @@ import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs for an RCCL run")]
+pytestmark = pytest.mark.gpu
+needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs for an RCCL run")
 
 DP_WORKER = r"""
 import os, sys
@@ -29,8 +29,10 @@ from video2music_amd import synthetic, dist as vdist
 from video2music_amd.model.video_music_transformer import VideoMusicTransformer
 from tests.helpers import CFG1, synthetic_sd, feats_t
 
-rank, world, local = vdist.init("nccl")
-dev = torch.device("cuda", local)
+backend = os.environ.get("AMT_TEST_BACKEND", "nccl")          # "gloo": the same worker with both ranks on one GPU
+rank, world, local = vdist.init(backend)
+dev = torch.device("cuda", local % torch.cuda.device_count())
+torch.cuda.set_device(dev)
 m = VideoMusicTransformer(**CFG1).eval()
 m.load_state_dict(synthetic_sd(CFG1), strict=False)
 m = m.to(dev)
@@ -46,7 +48,7 @@ full = vdist.all_gather_sequences(gen(slice(lo, hi)), n_clips)
 assert full.is_cuda and full.shape == (n_clips, T)
 want = gen(slice(0, n_clips))                      # the single-rank run over all clips
 assert torch.equal(full, want), (rank, (full != want).nonzero()[:4])
-t = torch.tensor([float(rank + 1)], dtype=torch.float64, device=dev)
+t = torch.tensor([float(rank + 1)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
 dist.all_reduce(t, op=dist.ReduceOp.MAX)           # the bench's MAX-over-ranks reduction
 assert float(t) == world
 dist.barrier(); dist.destroy_process_group()
@@ -96,23 +98,33 @@ def run_ranks(tmp_path, text, world=2, **extra):
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), AMT_ROOT=ROOT, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
-        env.pop("AMT_DIST_BACKEND", None)
+        if "AMT_DIST_BACKEND" not in extra:
+            env.pop("AMT_DIST_BACKEND", None)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
 
 
+@needs_two_gpus
 @pytest.mark.parametrize("n_clips", [6, 5])        # even and ragged shards
 def test_data_parallel_generate_over_rccl(tmp_path, n_clips):
     run_ranks(tmp_path, DP_WORKER, N_CLIPS=str(n_clips))
 
 
+@pytest.mark.parametrize("n_clips", [6, 5])
+def test_data_parallel_generate_two_ranks_one_gpu_gloo(tmp_path, n_clips):
+    """The same worker on a one-GPU box: both ranks generate their shard on cuda:0, the gather goes through gloo (host staging)."""
+    run_ranks(tmp_path, DP_WORKER, N_CLIPS=str(n_clips), AMT_TEST_BACKEND="gloo", AMT_DIST_BACKEND="gloo")
+
+
+@needs_two_gpus
 @pytest.mark.parametrize("shared", [False, True])
 def test_expert_parallel_moe_over_rccl(tmp_path, shared):
     run_ranks(tmp_path, EP_WORKER, SHARED=str(int(shared)))
 
 
+@needs_two_gpus
 def test_second_device_after_the_first():
     """One process, cuda:0 then cuda:1: config 2's K >= 1024 skinny GEMMs need the dynamic-LDS opt-in on each device."""
     from tests.helpers import CFG2, synthetic_sd, feats_t
