@@ -34,7 +34,7 @@ def test_bad_config_is_rejected_without_a_gpu():
     h = ctypes.c_void_p()
     with pytest.raises(_lib.AmtError, match="amt_create"):
         _lib.call("amt_create", ctypes.byref(cfg), ctypes.byref(h))
-    cfg = _lib.AmtConfig(6, 8, 512, 1024, 300, 300, 1287, 64)        # more than 32 clips per decode batch
+    cfg = _lib.AmtConfig(6, 8, 512, 1024, 300, 300, 1287, 257)       # more than 256 clips per decode chain (32 in round 1)
     with pytest.raises(_lib.AmtError, match="max_batch"):
         _lib.call("amt_create", ctypes.byref(cfg), ctypes.byref(h))
 
