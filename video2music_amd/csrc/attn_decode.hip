@@ -107,8 +107,18 @@ __device__ __forceinline__ void stream_keys(Batch<HD>& cur, Batch<HD>& nxt, cons
 constexpr int UCH = 4;           // folded prologue: the pre-LN row has at most UCH*256 floats
 
 // FOLD: 0 plain query, 1 folded-LayerNorm prologue, 2 the same plus the new key/value of this position
+#ifdef AMT_STAMPS
+#define ASTAMP(i) do { __builtin_amdgcn_sched_barrier(0); st_[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define ASTAMP(i) do { } while (0)
+#endif
+
 template <int HD, bool RPR, bool NT, int FOLD>
 __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnDecodeParams p) {
+#ifdef AMT_STAMPS
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    ASTAMP(0);
     constexpr int LPK = HD / 4;          // lanes per key row
     constexpr int KPW = 64 / LPK;        // keys per wave-instruction
     constexpr int STRIDE = NW * KPW * UNROLL;     // keys per workgroup batch
@@ -129,6 +139,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnDecodeParams p
     int j0 = wave * KPW;
     const int t = p.pos ? *p.pos : (p.n_keys - 1);   // issued here: the prologue's stores would pin it behind them
     float4 q4, kn4 = make_float4(0.f, 0.f, 0.f, 0.f), vn4 = kn4;
+    constexpr bool fresh = FOLD == 2;             // key/value of position t live in registers, not in the cache
+    const int n_keys = fresh ? t : t + 1;
+    const float* eb = RPR ? p.Er + (size_t)(p.er_len - 1 - t) * HD : nullptr;   // Er row of key 0 (wave-uniform)
     // Vector loads return in issue order.  The long prologue of FOLD 2 (11 loads and their address math) goes
     // behind the first K/V batch so that the stream starts at once; the short one of FOLD 1 goes in front of it
     // so that the statistics are computed while the batch is in flight (measured both ways).
@@ -154,6 +167,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnDecodeParams p
             rv = ld4(raw + 2 * d); gv = ld4(p.fold_g + 2 * d + col); cv = ld4(p.fold_c + 2 * d + col);
         }
         if (FOLD == 1) load_kv<HD, NT>(b0, kb, vb, j0, sub, c4, p.cap);
+        // the first batch's Er rows need only the position: issued behind the prologue's loads, they land while the
+        // statistics are reduced instead of costing one more L2 round trip after the query exists
+        if (RPR && FOLD == 2) load_er<HD>(b0, eb, j0, sub, c4, n_keys);
         const float inv_d = 1.0f / (float)d;
         float s = 0.f;
 #pragma unroll
@@ -190,14 +206,15 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnDecodeParams p
             }
         }
     }
-    constexpr bool fresh = FOLD == 2;             // key/value of position t live in registers, not in the cache
-    const int n_keys = fresh ? t : t + 1;
-    const float* eb = RPR ? p.Er + (size_t)(p.er_len - 1 - t) * HD : nullptr;   // Er row of key 0 (wave-uniform)
+#ifdef AMT_STAMPS
+    if (q4.x == 1.2345e-30f) st_[7] = 1;          // stamp 1 = the query exists (prologue loads landed, statistics done)
+#endif
+    ASTAMP(1);
     if (fresh && wave == 0 && sub == 0) {
         st4(p.k_new + (((size_t)b * p.H + h) * p.cap + t) * HD + c * 4, kn4);
         st4(p.v_new + (((size_t)b * p.H + h) * p.cap + t) * HD + c * 4, vn4);
     }
-    if (RPR) load_er<HD>(b0, eb, j0, sub, c4, n_keys);
+    if (RPR && FOLD != 2) load_er<HD>(b0, eb, j0, sub, c4, n_keys);
     float m = -INFINITY, l = 0.f;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!RPR) {
@@ -230,6 +247,10 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnDecodeParams p
         }
     }
 
+#ifdef AMT_STAMPS
+    if (l == 1.2345e-30f) st_[7] = 2;             // stamp 2 = this wave's keys are consumed
+#endif
+    ASTAMP(2);
     // merge the KPW lane groups of the wave (lanes with equal c)
 #pragma unroll
     for (int off = LPK; off < 64; off <<= 1) {
@@ -249,7 +270,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnDecodeParams p
         if (c == 0) { sm_m[wave] = m; sm_l[wave] = l; }
         st4(&sm_o[wave][c * 4], o);
     }
+    ASTAMP(3);
     __syncthreads();
+    ASTAMP(4);
     if (wave == 0 && sub == 0) {
         float mn = sm_m[0];
 #pragma unroll
@@ -267,6 +290,13 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnDecodeParams p
         ot.x *= inv; ot.y *= inv; ot.z *= inv; ot.w *= inv;
         st4(p.o + ((size_t)b * p.H + h) * HD + c * 4, ot);
     }
+#ifdef AMT_STAMPS
+    ASTAMP(5);
+    if (p.stamps && threadIdx.x == 0) {
+        unsigned long long* o = p.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        for (int i = 0; i < 8; ++i) o[i] = st_[i];
+    }
+#endif
 }
 
 template <int HD, int FOLD>

@@ -87,6 +87,7 @@ struct AttnDecodeParams {
     const float* fold_u; const float* fold_g; const float* fold_c; const float* fold_lnw; const float* fold_lnb;
     float* xn; int ldq, d, new_kv; float eps, q_scale;
     float* k_new; float* v_new;   // the (writable) cache when new_kv
+    unsigned long long* stamps;   // diagnostic builds only (-DAMT_STAMPS): [workgroup][8] s_memrealtime stamps; null in the library
 };
 int32_t amt_launch_attn_decode(const AttnDecodeParams& p, hipStream_t stream);
 
