@@ -104,6 +104,8 @@ int32_t amt_generate_run(amt_handle* h, int32_t n_steps, float* logits_out, void
  *   table instead of root + attr embeddings.  The caller uploads that table (n_rows, d) under the name "embedding_root.weight" and
  *   an all-zero (16, d) "embedding_attr.weight", passes chord ids as the root ids and zeros as the attr ids; the generated id then
  *   feeds back as the root index in both decision branches. */
+/*   "causal_mask" = 0 (any time): amt_prefill runs the decoder self-attention without the subsequent mask (reference
+ *   forward(mask=False), :978-982); 1 restores the default. */
 int32_t amt_set_option(amt_handle* h, const char* name, int32_t value);
 /* amt_encode with rows [B*S][d] added to Linear_vis's output before the encoder: reference scene_embed=True
  * (:1016-1027: the scene offset is left out of the feature columns and scene_embedding(offset.int()) is added instead).  The
@@ -119,6 +121,11 @@ int32_t amt_generate_profile(amt_handle* h, int32_t n_steps, double* ms_by_class
  * chosen ids (B) int64 back. */
 int32_t amt_generate_step_probs(amt_handle* h, float* probs_out, void* stream);
 int32_t amt_generate_commit(amt_handle* h, const int64_t* chosen, void* stream);
+/* Between the steps of a host-driven generation (amt_generate_step_probs / amt_generate_commit): the branch of the following
+ * steps, 0 = sampling branch (suppressions applied to the distribution, the committed id feeds back as root / attr), 1 = top-k
+ * branch (plain softmax[:157], root / attr of the committed position stay PAD).  This is the per-step choice
+ * `random.uniform(0,1) <= beam_chance` of model/video_music_transformer.py:1074-1084; the host keeps the `beam` rows. */
+int32_t amt_generate_set_branch(amt_handle* h, int32_t beam);
 /* Copies the (B,T) int64 token matrix (PAD=158 beyond the generated length) to tokens_out. */
 int32_t amt_generate_end(amt_handle* h, int64_t* tokens_out, void* stream);
 /* begin + run(-1) + end. */
@@ -163,6 +170,10 @@ int32_t amt_rpr_attn_fwd(const float* q, const float* k, const float* v, const f
                          int32_t B, int32_t H, int32_t L, int32_t hd, int32_t er_len, void* stream);
 /* Core of torch MultiheadAttention as used at rpr.py:62-63 / the video encoder: q (B,Lq,H*hd)
  * scaled, k,v (B,Lk,H*hd); no mask (causal=0) or causal. */
+/* The same attention without the causal mask (forward(mask=False), model/video_music_transformer.py:978-982): every key is
+ * visible; the relative term stays zero for keys j > i, which is what model/rpr.py:439-455 (_skew) produces. */
+int32_t amt_rpr_attn_nomask_fwd(const float* q, const float* k, const float* v, const float* Er, float* o,
+                                int32_t B, int32_t H, int32_t L, int32_t hd, int32_t er_len, void* stream);
 int32_t amt_cross_attn_fwd(const float* q, const float* k, const float* v, float* o,
                            int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd, int32_t causal, void* stream);
 /* General strided form of the same kernel (used by the V2 stack and MultiheadGQA): tensor[b][h][l][c] lives at

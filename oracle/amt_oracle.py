@@ -189,11 +189,11 @@ def chord_stream(sd, x_root, x_attr, key):
     return x + positional_encoding(L, d, x.dtype)
 
 
-def decode(sd, H, x, memory, collect=None):
+def decode(sd, H, x, memory, collect=None, causal=True):
     """model/rpr.py:24-35,55-70: 6 x post-norm (RPR self-attn, cross-attn, ReLU FFN) + final LN."""
     for i in range(n_layers_of(sd, "decoder")):
         p = f"transformer.decoder.layers.{i}."
-        x = layer_norm(x + rpr_self_attention(x, sd, p + "self_attn.", H), sd[p + "norm1.weight"], sd[p + "norm1.bias"])
+        x = layer_norm(x + rpr_self_attention(x, sd, p + "self_attn.", H, causal), sd[p + "norm1.weight"], sd[p + "norm1.bias"])
         x = layer_norm(x + mha(x, memory, sd, p + "multihead_attn.", H), sd[p + "norm2.weight"], sd[p + "norm2.bias"])
         ff = linear(torch.relu(linear(x, sd[p + "linear1.weight"], sd[p + "linear1.bias"])),
                     sd[p + "linear2.weight"], sd[p + "linear2.bias"])
@@ -203,12 +203,15 @@ def decode(sd, H, x, memory, collect=None):
     return layer_norm(x, sd["transformer.decoder.norm.weight"], sd["transformer.decoder.norm.bias"])
 
 
-def forward(sd, H, x_root, x_attr, sem, key, scene_off, motion, emotion, collect=None):
-    """VideoMusicTransformer.forward (model/video_music_transformer.py:978-1044), mask=True,
-    IS_SEPERATED=False: logits (B,L,159)."""
+def forward(sd, H, x_root, x_attr, sem, key, scene_off, motion, emotion, collect=None, mask=True, separated=False):
+    """VideoMusicTransformer.forward (model/video_music_transformer.py:978-1044): logits (B,L,159); ``separated`` = IS_SEPERATED
+    (:968-973, 1036-1040): the pair (y_root, y_attr) from the Wout_root / Wout_attr heads.  mask=False drops the causal mask (:978-982; the
+    relative term stays zero above the diagonal, that is `_skew`'s doing)."""
     memory = encode(sd, H, sem, scene_off, motion, emotion)
     xf = chord_stream(sd, x_root, x_attr, key)
-    out = decode(sd, H, xf, memory, collect)
+    out = decode(sd, H, xf, memory, collect, causal=mask is True)
+    if separated:
+        return linear(out, sd["Wout_root.weight"], sd["Wout_root.bias"]), linear(out, sd["Wout_attr.weight"], sd["Wout_attr.bias"])
     return linear(out, sd["Wout.weight"], sd["Wout.bias"])
 
 
@@ -221,15 +224,19 @@ def root_attr_of(tok):
 
 def generate(sd, H, sem, key, scene_off, motion, emotion, primer, primer_root, primer_attr,
              target_seq_length=300, beam=0, max_conseq_N=0, max_conseq_chord=2, margins=None, forward_fn=None,
-             temperature=1.0):
+             temperature=1.0, beam_chance=1.0, rng=None):
     """VideoMusicTransformer.generate (model/video_music_transformer.py:1046-1132), one clip,
     full re-forward every step exactly like the reference (no KV cache, encoder re-run).
 
     beam=1 -> G1 (verbatim top-1 branch :1078-1084: root/attr never updated, no suppression).
     beam=0 -> G2: the sampling branch :1085-1128 with ``Categorical.sample`` replaced by
     arg-max of the normalised probabilities.
-    Returns int64 (1, T).  ``margins`` (list) receives top1-top2 of the decision distribution.
+    beam>1 / beam_chance<1 (:1074-1084 as written): ``rng.uniform(0, 1) <= beam_chance`` (python's ``random`` in the reference)
+    picks the branch per step; the top-k branch replicates row 0 ``beam`` times and writes the k best ids into column cur.
+    Returns int64 (max(beam,1), T).  ``margins`` (list) receives top1-top2 of the decision distribution.
     """
+    import random as _random
+    rng = rng or _random
     T = target_seq_length
     gen = torch.full((1, T), CHORD_PAD, dtype=torch.long)
     gen_root = torch.full((1, T), CHORD_ROOT_PAD, dtype=torch.long)
@@ -246,11 +253,14 @@ def generate(sd, H, sem, key, scene_off, motion, emotion, primer, primer_root, p
         logits = (forward_fn or forward)(sd, H, gen_root[:, :cur], gen_attr[:, :cur], sem, key, scene_off, motion, emotion)
         y = torch.softmax(logits / temperature, dim=-1)[..., :CHORD_END]
         probs = y[:, cur - 1, :].clone()
-        if beam > 0:
-            tok = int(torch.topk(probs.flatten(), 1)[1][0]) % CHORD_SIZE
-            gen[0, cur] = tok
+        beam_ran = 2.0 if beam == 0 else rng.uniform(0, 1)
+        if beam_ran <= beam_chance:
+            top_i = torch.topk(probs.flatten(), beam)[1]
+            gen = gen[top_i // CHORD_SIZE, :]
+            gen[..., cur] = top_i % CHORD_SIZE
             if ids_feed:
-                gen_root[0, cur] = tok
+                assert beam == 1, "chord_embed with beam > 1 feeds `beam` rows against one clip of features: fails in the reference"
+                gen_root[0, cur] = gen[0, cur]
         else:
             if max_conseq_N == 0:
                 probs[0, 0] = 0.0
@@ -266,7 +276,7 @@ def generate(sd, H, sem, key, scene_off, motion, emotion, primer, primer_root, p
             tok = int(pn.argmax(-1))
             probs = pn
             r, a = (tok, 0) if ids_feed else root_attr_of(tok)
-            gen[0, cur] = tok
+            gen[:, cur] = tok
             gen_root[0, cur] = r
             gen_attr[0, cur] = a
         if margins is not None:

@@ -98,6 +98,24 @@ def test_rpr_attention_prefill(B, H, L, hd, er_len):
     assert (o.cpu().double() - ref).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("B,H,L,hd,er_len", [(1, 4, 1, 32, 300), (2, 4, 12, 32, 300), (2, 4, 33, 32, 300), (2, 8, 129, 64, 200),
+                                            (1, 8, 300, 64, 300), (1, 2, 257, 64, 1024), (1, 2, 70, 128, 128), (1, 8, 1024, 64, 1024)])
+def test_rpr_attention_prefill_without_causal_mask(B, H, L, hd, er_len):
+    """forward(mask=False) of the reference (model/video_music_transformer.py:978-982): all keys visible, and `_skew`
+    (model/rpr.py:439-455, verbatim in the oracle) leaves the relative term zero above the diagonal."""
+    rs = np.random.RandomState(1000 + L)
+    E = H * hd
+    q, k, v = rnd(rs, B, L, E, scale=0.5), rnd(rs, B, L, E), rnd(rs, B, L, E)
+    Er = torch.from_numpy(rs.uniform(size=(er_len, hd)).astype(np.float32))
+    qh, kh, vh = (O.split_heads(t.double(), H) for t in (q, k, v))
+    s = qh @ kh.transpose(-1, -2) + O.skew(torch.einsum("bhld,md->bhlm", qh, Er.double()[er_len - L:]))
+    ref = O.merge_heads(torch.softmax(s, -1) @ vh)
+    o = torch.empty(B, L, E, device="cuda")
+    dq, dk, dv, de = dev(q), dev(k), dev(v), dev(Er)
+    _lib.call("amt_rpr_attn_nomask_fwd", _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(de), _lib.ptr(o), B, H, L, hd, er_len, sp())
+    assert (o.cpu().double() - ref).abs().max() < 2e-5
+
+
 @pytest.mark.parametrize("B,H,Lq,Lk,hd,causal", [(2, 4, 5, 300, 32, 0), (1, 8, 300, 300, 64, 0), (2, 8, 130, 77, 64, 0),
                                                 (2, 8, 64, 64, 64, 1), (1, 2, 33, 100, 128, 0)])
 def test_cross_attention_prefill(B, H, Lq, Lk, hd, causal):

@@ -273,3 +273,41 @@ def test_base_model_chord_embed_scene_embed(golden, tag):
     margins = []
     assert np.array_equal(O.generate(*args, target_seq_length=32, beam=0, margins=margins).numpy(), g[f"{tag}_g2"])
     assert np.abs(np.array(margins) - g[f"{tag}_g2_margins"]).max() < 1e-4 and min(margins) > 1e-2
+
+
+# ---------------- rarely used options of the reference classes (oracle/make_goldens_opts.py; VERDICT r1 missing #5) ----------------
+
+@pytest.mark.parametrize("tag", ["beam3", "beam2_c05", "beam1_c03", "beam4_c07"])
+def test_beam_and_beam_chance(golden, tag):
+    """generate with beam > 1 / beam_chance < 1 as the reference code behaves (model/video_music_transformer.py:1074-1084)."""
+    import random
+    g = golden("g_opts.npz")
+    beam, chance, seed, T = g[f"{tag}_args"]
+    assert float(g[f"{tag}_min_gap"]) > 0.05                 # relative gap between neighbouring ranks of every top-k decision
+    sd = synthetic_sd(CFG1, recipe="feedback")
+    f = feats_t(synthetic.synthetic_features(3, seed=1234), slice(0, 1), key=g["key"])
+    rng = random.Random(int(seed))
+    ids = O.generate(sd, 4, f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], torch.tensor([1, 30]), torch.tensor([1, 3]),
+                     torch.tensor([0, 4]), target_seq_length=int(T), beam=int(beam), beam_chance=float(chance), rng=rng)
+    assert ids.shape == (int(beam), int(T)) and np.array_equal(ids.numpy(), g[f"{tag}_ids"])
+
+
+@pytest.mark.parametrize("B,L", [(1, 12), (2, 33), (1, 130)])
+def test_forward_without_causal_mask(golden, B, L):
+    g = golden("g_opts.npz")
+    sd = synthetic_sd(CFG1, recipe="feedback")
+    f = feats_t(synthetic.synthetic_features(3, seed=1234), slice(0, B), key=g["key"])
+    lg = O.forward(sd, 4, torch.from_numpy(g[f"nomask_root_B{B}_L{L}"]), torch.from_numpy(g[f"nomask_attr_B{B}_L{L}"]), f["semantic"], f["key"],
+                   f["scene_offset"], f["motion"], f["emotion"], mask=False)
+    assert np.abs(lg.numpy() - g[f"nomask_logits_B{B}_L{L}"]).max() < 5e-4      # logits of magnitude ~130 with this recipe
+
+
+def test_separated_heads(golden):
+    g = golden("g_opts.npz")
+    keys = set(g["sep_keys"].tolist())
+    assert {"Wout_root.weight", "Wout_attr.bias", "Wout.weight"} <= keys        # the base class always holds the three heads (:973-975)
+    sd = synthetic_sd(CFG1)
+    f = feats_t(synthetic.synthetic_features(3, seed=1234), slice(0, 2), key=g["key"])
+    yr, ya = O.forward(sd, 4, torch.from_numpy(g["sep_root"]), torch.from_numpy(g["sep_attr"]), f["semantic"], f["key"], f["scene_offset"],
+                       f["motion"], f["emotion"], separated=True)
+    assert np.abs(yr.numpy() - g["sep_y_root"]).max() < TOL and np.abs(ya.numpy() - g["sep_y_attr"]).max() < TOL

@@ -43,6 +43,7 @@ SIGNATURES = {
     "amt_generate_profile": [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _P],
     "amt_generate_step_probs": [_P, _P, _P],
     "amt_generate_commit": [_P, _P, _P],
+    "amt_generate_set_branch": [_P, _I],
     "amt_generate_end": [_P, _P, _P],
     "amt_generate": [_P, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P],
     "amt_v2_decide_batch": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P],
@@ -56,6 +57,7 @@ SIGNATURES = {
     "amt_add_fwd": [_P, _P, _P, C.c_int64, _P],
     "amt_rope_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "amt_rpr_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "amt_rpr_attn_nomask_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "amt_cross_attn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "amt_attn_fwd": [_P, _P, _P, _P, C.POINTER(C.c_int64), _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "amt_concat_features_fwd": [_P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _P],

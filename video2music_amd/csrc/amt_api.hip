@@ -102,6 +102,7 @@ struct amt_handle {
     int genB = 0, genT = 0, genP = 0, beam = 0, mcN = 0, mcC = 2, steps_done = 0;
     int n_root = 15;                     // rows of the "root" input table: 15 chord roots, or the chord-embedding table's rows (chord_embed)
     bool chord_embed = false;            // amt_set_option("chord_embed"): the chord id is the input index and feeds back
+    bool causal_mask = true;             // amt_set_option("causal_mask"): 0 = the forward without the subsequent mask (mask=False)
     const float* vis_resid = nullptr;    // amt_encode_resid: rows added to Linear_vis's output (scene_embed)
     int skip_mask = 0;                   // bench-only ablation: 1 = no self-attention launches, 2 = no cross-attention launches
     bool gen_active = false;
@@ -670,6 +671,10 @@ extern "C" int32_t amt_set_option(amt_handle* h, const char* name, int32_t value
         h->chord_embed = value != 0;
         return 0;
     }
+    if (strcmp(name, "causal_mask") == 0) {                  // run-time switch of amt_prefill (forward(mask=False), :978-982)
+        h->causal_mask = value != 0;
+        return 0;
+    }
     AMT_CHECK_ARG(false, "amt_set_option: unknown option '%s'", name);
     return -1;
 }
@@ -760,7 +765,7 @@ extern "C" int32_t amt_prefill(amt_handle* h, int32_t B, int32_t L, const int64_
         a.q = h->wsQKV; a.k = h->wsQKV + d; a.v = h->wsQKV + 2 * d; a.o = h->wsO;
         a.q_bs = a.k_bs = a.v_bs = (size_t)L * 3 * d; a.q_hs = a.k_hs = a.v_hs = h->hd; a.q_ls = a.k_ls = a.v_ls = 3 * d;
         a.o_bs = (size_t)L * d; a.o_hs = h->hd; a.o_ls = d;
-        a.B = B; a.H = h->H; a.Lq = L; a.Lk = L; a.hd = h->hd; a.causal = 1; a.Er = D.Er; a.er_len = h->Tcap; a.kv_group = 1;
+        a.B = B; a.H = h->H; a.Lq = L; a.Lk = L; a.hd = h->hd; a.causal = h->causal_mask ? 1 : 0; a.Er = D.Er; a.er_len = h->Tcap; a.kv_group = 1;
         if ((rc = amt_launch_attn_prefill(a, s))) return rc;
         if ((rc = proj_resid_ln(h, h->wsO, d, D.sa_ow, D.sa_ob, h->wsX, D.n1w, D.n1b, nullptr, nullptr, h->wsU, h->wsX, R, s))) return rc;
         // cross-attention: q from the chord stream, K/V precomputed per clip by amt_encode
@@ -922,6 +927,13 @@ extern "C" int32_t amt_generate_commit(amt_handle* h, const int64_t* chosen, voi
     return 0;
 }
 
+extern "C" int32_t amt_generate_set_branch(amt_handle* h, int32_t beam) {
+    AMT_CHECK_ARG(h && h->gen_active, "amt_generate_set_branch: no generation in progress");
+    AMT_CHECK_ARG(beam == 0 || beam == 1, "amt_generate_set_branch: branch %d (0 = sampling branch, 1 = top-k branch)", beam);
+    h->beam = beam;
+    return 0;
+}
+
 extern "C" int32_t amt_generate_end(amt_handle* h, int64_t* tokens_out, void* stream) {
     AMT_CHECK_ARG(h && h->gen_active && tokens_out, "amt_generate_end: no generation in progress");
     AMT_HIP(hipMemcpyAsync(tokens_out, h->tokens, (size_t)h->genB * h->genT * sizeof(int64_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -1013,6 +1025,14 @@ extern "C" int32_t amt_rpr_attn_fwd(const float* q, const float* k, const float*
     AMT_CHECK_ARG(q && k && v && Er && o, "amt_rpr_attn_fwd: null pointer");
     AttnParams a = blh_params(q, k, v, o, B, H, L, L, hd);
     a.causal = 1; a.Er = Er; a.er_len = er_len;
+    return amt_launch_attn_prefill(a, (hipStream_t)stream);
+}
+
+extern "C" int32_t amt_rpr_attn_nomask_fwd(const float* q, const float* k, const float* v, const float* Er, float* o,
+                                           int32_t B, int32_t H, int32_t L, int32_t hd, int32_t er_len, void* stream) {
+    AMT_CHECK_ARG(q && k && v && Er && o, "amt_rpr_attn_nomask_fwd: null pointer");
+    AttnParams a = blh_params(q, k, v, o, B, H, L, L, hd);
+    a.causal = 0; a.Er = Er; a.er_len = er_len;
     return amt_launch_attn_prefill(a, (hipStream_t)stream);
 }
 

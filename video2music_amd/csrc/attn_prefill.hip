@@ -127,8 +127,12 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
         //      aligned chunks k-1 and k of 32 distances each; chunk c holds R^T[m][query] = Er[er_len-1-(32c+m)] . q.
         //      Tiles are visited with k descending, so chunk k was produced by the previous tile (as its k-1) and
         //      only chunk k-1 is new: one extra MFMA tile per key tile, kept in a 2-slot per-wave LDS ring. ----
-        if constexpr (RPR) {
+        // Without the causal mask (forward(mask=False), model/video_music_transformer.py:978-982) the tiles above the
+        // diagonal are visible too; `_skew` (model/rpr.py:439-455) leaves the relative term ZERO for every key j > i, so those
+        // tiles (k < 0) and the upper half of the diagonal tile (k == 0, distance < 0) take the plain Q.K score.
+        if constexpr (RPR) if (i0 >= j0) {
             const int k = (i0 - j0) / 32;
+            const bool upper0 = !p.causal && k == 0;
             // The Er rows of a chunk come straight from L2 (the table is shared by every clip and head).  The rows of the NEXT
             // tile's chunk (k-2) are requested as soon as this tile's fragments are in the matrix pipe, so their latency
             // overlaps the softmax and the PV product instead of stalling the next tile.
@@ -168,7 +172,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
                 const int krow = (e & 3) + 8 * (e >> 2) + 4 * lh;
                 const int dlt = li - krow;                  // distance - D
                 const int c = dlt >= 0 ? k : k - 1;
-                sacc[e] += scr[(c & 1) * (32 * 33) + li * 33 + (dlt & 31)];
+                const float r = scr[(c & 1) * (32 * 33) + li * 33 + (dlt & 31)];
+                sacc[e] += (upper0 && dlt < 0) ? 0.f : r;
             }
         }
 
@@ -391,8 +396,8 @@ int32_t launch_hd(const AttnParams& p, hipStream_t stream) {
 int32_t amt_launch_attn_prefill(const AttnParams& p, hipStream_t stream) {
     AMT_CHECK_ARG(p.B > 0 && p.H > 0 && p.Lq > 0 && p.Lk > 0, "attn_prefill: bad shape");
     AMT_CHECK_ARG(p.kv_group >= 1 && p.H % p.kv_group == 0, "attn_prefill: bad kv_group %d", p.kv_group);
-    AMT_CHECK_ARG(p.Er == nullptr || (p.causal && p.Lq == p.Lk && p.Lq <= p.er_len),
-                  "attn_prefill: relative positions need causal self-attention with L=%d <= er_len=%d", p.Lq, p.er_len);
+    AMT_CHECK_ARG(p.Er == nullptr || (p.Lq == p.Lk && p.Lq <= p.er_len),
+                  "attn_prefill: relative positions need self-attention with L=%d <= er_len=%d", p.Lq, p.er_len);
     AMT_CHECK_ARG(p.q_ls % 4 == 0 && p.k_ls % 4 == 0 && p.v_ls % 4 == 0, "attn_prefill: row strides must be multiples of 4 floats");
     switch (p.hd) {
         case 32: launch_hd<32>(p, stream); break;

@@ -199,7 +199,7 @@ class VideoMusicTransformer(nn.Module):
                 _lib.call("amt_set_option", h, b"chord_embed", 1)
             self._handle = h
             self._weights_sig = None
-        sig = tuple((k, v.data_ptr(), v._version) for k, v in self.state_dict().items())
+        sig = tuple((k, v.data_ptr(), v._version) for k, v in self.state_dict().items()) + (bool(IS_SEPERATED),)
         if sig != self._weights_sig:
             torch.cuda.synchronize(dev)
             for name, t in self.state_dict().items():
@@ -207,6 +207,13 @@ class VideoMusicTransformer(nn.Module):
                 if name == "Linear_vis.weight" and self.scene_embed:
                     c = self._scene_col
                     t = torch.cat([t[:, :c], torch.zeros(t.shape[0], 1, device=t.device), t[:, c:]], dim=1).contiguous()
+                if IS_SEPERATED and name in ("Wout.weight", "Wout.bias"):
+                    # IS_SEPERATED (utilities/constants.py:11; reference :1036-1040): the two small heads ride in the rows of the
+                    # library's one output projection (root rows 0..14, attr rows 15..30, the rest zero); forward() splits them
+                    part = name.split(".")[1]
+                    r, a = getattr(self.Wout_root, part).detach(), getattr(self.Wout_attr, part).detach()
+                    t = torch.zeros_like(t)
+                    t[:CHORD_ROOT_SIZE], t[CHORD_ROOT_SIZE:CHORD_ROOT_SIZE + CHORD_ATTR_SIZE] = r.to(t), a.to(t)
                 if self.chord_embed:                 # the chord table takes the root table's place, the attr table is all zero
                     if name == "embedding_root.weight":
                         t = self.chord_embedding_model.weight.detach().to(torch.float32).contiguous()
@@ -273,11 +280,10 @@ class VideoMusicTransformer(nn.Module):
                 feature_motion, feature_emotion, mask=True):
         """Teacher-forced pass, reference ``forward`` (:978-1044).  Returns logits (B,L,159) fp32.
 
-        ``x`` is only used for its shape, like in the reference (:985-987 consume root/attr).
+        ``x`` is only used for its shape, like in the reference (:985-987 consume root/attr).  ``mask`` other than True
+        drops the subsequent mask of the decoder self-attention (:978-982; no reference caller does).  With the module
+        constant IS_SEPERATED set, the pair (y_root (B,L,15), y_attr (B,L,16)) of the Wout_root / Wout_attr heads (:1036-1040).
         """
-        if mask is not True:
-            raise NotImplementedError("forward(mask=False) is not part of the hot path; every reference caller "
-                                      "uses the causal mask (utilities/run_model_vevo.py:84-91)")
         dev = self._device()
         B, L = x.shape[0], x.shape[1]
         sem, key, scene, motion, emotion, Bf, S = self._prep_features(feature_semantic_list, feature_key,
@@ -294,10 +300,15 @@ class VideoMusicTransformer(nn.Module):
             nb = sl.stop - sl.start
             self._encode(h, sem, scene, motion, emotion, sl)
             out = logits[sl]
-            _lib.call("amt_prefill", h, nb, L, _lib.ptr(roots[sl].contiguous()), _lib.ptr(attrs[sl].contiguous()),
-                      _lib.ptr(key[sl].contiguous()), _lib.ptr(out), None, -1, _lib.stream_ptr())
+            _lib.call("amt_set_option", h, b"causal_mask", int(mask is True))
+            try:
+                _lib.call("amt_prefill", h, nb, L, _lib.ptr(roots[sl].contiguous()), _lib.ptr(attrs[sl].contiguous()),
+                          _lib.ptr(key[sl].contiguous()), _lib.ptr(out), None, -1, _lib.stream_ptr())
+            finally:
+                _lib.call("amt_set_option", h, b"causal_mask", 1)
         if IS_SEPERATED:
-            raise NotImplementedError("IS_SEPERATED heads are disabled in the reference (utilities/constants.py:11)")
+            return (logits[..., :CHORD_ROOT_SIZE].contiguous(),
+                    logits[..., CHORD_ROOT_SIZE:CHORD_ROOT_SIZE + CHORD_ATTR_SIZE].contiguous())
         return logits
 
     def forward_debug(self, x_root, x_attr, feature_semantic_list, feature_key, feature_scene_offset,
@@ -326,9 +337,68 @@ class VideoMusicTransformer(nn.Module):
         """Reference ``generate`` (:1046-1132) for one clip: returns a LongTensor (1, target_seq_length)."""
         assert (not self.training), "Cannot generate while in training mode"
         print("Generating sequence of max length:", target_seq_length)
+        if beam > 1 or (beam == 1 and beam_chance < 1.0):      # (beam, T): the k best ids of the last top-k step ride in rows 1..
+            return self._generate_mixed(feature_semantic_list, feature_key, feature_scene_offset, feature_motion, feature_emotion,
+                                        primer, primer_root, primer_attr, target_seq_length, beam, beam_chance, max_conseq_N,
+                                        max_conseq_chord, sampler, clip=0)
         return self.generate_batch(feature_semantic_list, feature_key, feature_scene_offset, feature_motion,
                                    feature_emotion, primer, primer_root, primer_attr, target_seq_length, beam,
                                    beam_chance, max_conseq_N, max_conseq_chord, sampler)[:1]
+
+    def _generate_mixed(self, feature_semantic_list, feature_key, feature_scene_offset, feature_motion, feature_emotion,
+                        primer, primer_root, primer_attr, target_seq_length, beam, beam_chance, max_conseq_N, max_conseq_chord,
+                        sampler, clip=0):
+        """``generate`` with beam > 1 and / or beam_chance < 1 as the reference code behaves (:1074-1084), one clip, host-driven
+        (no reference caller takes this path; generate.py:347-349 asserts beam == 0).  Per step ``random.uniform(0, 1) <=
+        beam_chance`` (python's ``random``, as in the reference: ``random.seed`` pins it) picks the branch.  Top-k branch: the
+        forward consumes root / attr only, so the batch stays 1; ``gen_seq`` becomes ``beam`` copies of its row 0 with the k best
+        ids of softmax(...)[:157] in column cur, and root / attr of that position stay PAD.  Sampling branch: suppressions look
+        at row 0, the drawn id goes to every row and feeds back.  Returns LongTensor (beam, T)."""
+        import random
+        if IS_SEPERATED:
+            raise TypeError("softmax(): argument 'input' must be Tensor, not tuple (IS_SEPERATED heads, as in the reference)")
+        if self.chord_embed and beam > 1:
+            raise RuntimeError("chord_embed with beam > 1 feeds `beam` chord rows against one clip of video features: the "
+                               "reference fails in the cross-attention at the second step")
+        if sampler not in ("categorical", "multinomial", "argmax"):
+            raise ValueError(f"unknown sampler {sampler!r}")
+        dev = self._device()
+        sem, key, scene, motion, emotion, B, S = self._prep_features(feature_semantic_list, feature_key, feature_scene_offset,
+                                                                    feature_motion, feature_emotion)
+        h = self._ensure_handle(sem.shape[2])
+        T = int(target_seq_length)
+        prim = [torch.as_tensor(p).to(device=dev, dtype=torch.long).reshape(-1).contiguous() for p in (primer, primer_root, primer_attr)]
+        P = prim[0].numel()
+        if self.chord_embed:
+            prim[1], prim[2] = prim[0], torch.zeros_like(prim[0])
+        sl = slice(clip, clip + 1)
+        st = _lib.stream_ptr()
+        self._encode(h, sem, scene, motion, emotion, sl)
+        _lib.call("amt_generate_begin", h, 1, _lib.ptr(prim[0]), _lib.ptr(prim[1]), _lib.ptr(prim[2]), P, 0,
+                  _lib.ptr(key[sl].contiguous()), T, 0, int(max_conseq_N), int(max_conseq_chord), st)
+        gen = torch.full((1, T), CHORD_PAD, device=dev, dtype=torch.long)
+        gen[0, :P] = prim[0]
+        probs = torch.empty(1, CHORD_END, device=dev)
+        for cur in range(1, T):
+            if cur < P:                        # still inside the primer: the commit keeps the given token
+                _lib.call("amt_generate_step_probs", h, _lib.ptr(probs), st)
+                _lib.call("amt_generate_commit", h, _lib.ptr(gen[0, cur:cur + 1].contiguous()), st)
+                continue
+            beam_ran = 2.0 if beam == 0 else random.uniform(0, 1)
+            top_k = beam_ran <= beam_chance
+            _lib.call("amt_generate_set_branch", h, int(top_k))
+            _lib.call("amt_generate_step_probs", h, _lib.ptr(probs), st)
+            if top_k:
+                top_i = torch.topk(probs.flatten(), beam)[1]
+                gen = gen[top_i // CHORD_SIZE, :]
+                gen[..., cur] = top_i % CHORD_SIZE
+            elif sampler == "argmax":
+                gen[:, cur] = probs.argmax(-1)
+            else:                              # Categorical(probs).sample(), :1104-1105
+                gen[:, cur] = torch.multinomial(probs, 1).reshape(())
+            _lib.call("amt_generate_commit", h, _lib.ptr(gen[0, cur:cur + 1].contiguous()), st)
+        torch.cuda.synchronize(dev)
+        return gen
 
     def _debug_set_skip(self, mask):
         """bench.py only: leave the self- (1) / cross- (2) attention launches out of the decode step."""
@@ -380,15 +450,22 @@ class VideoMusicTransformer(nn.Module):
         instead of T-1 decode steps (``one_pass_top1=False`` or ``return_logits=True`` keep the step loop).
         """
         assert (not self.training), "Cannot generate while in training mode"
-        if beam not in (0, 1):
-            raise NotImplementedError("beam > 1 is not implemented (generate.py:347-349 asserts it out as well)")
-        if beam == 1 and beam_chance < 1.0:
-            raise NotImplementedError("beam_chance < 1 mixes the two branches at random; not a parity target")
+        if IS_SEPERATED:
+            raise TypeError("softmax(): argument 'input' must be Tensor, not tuple (IS_SEPERATED heads, as in the reference)")
         if sampler not in ("categorical", "multinomial", "argmax"):
             raise ValueError(f"unknown sampler {sampler!r}")
         dev = self._device()
         sem, key, scene, motion, emotion, B, S = self._prep_features(feature_semantic_list, feature_key,
                                                                     feature_scene_offset, feature_motion, feature_emotion)
+        if beam > 1 or (beam == 1 and beam_chance < 1.0):
+            # the reference's top-k branch is a one-clip affair (see _generate_mixed); clips run one after the other and row 0 of
+            # each (the top-1 row, the one every later step looks at) is returned
+            assert not return_logits, "return_logits belongs to the device-side step loop"
+            per_clip = torch.as_tensor(primer).dim() == 2
+            pick = (lambda p, c: torch.as_tensor(p)[c]) if per_clip else (lambda p, c: p)
+            return torch.cat([self._generate_mixed(sem, key, scene, motion, emotion, pick(primer, c), pick(primer_root, c),
+                                                   pick(primer_attr, c), target_seq_length, beam, beam_chance, max_conseq_N,
+                                                   max_conseq_chord, sampler, clip=c)[:1] for c in range(B)], dim=0)
         h = self._ensure_handle(sem.shape[2])
         T = int(target_seq_length)
         prim = [torch.as_tensor(p).to(device=dev, dtype=torch.long).contiguous() for p in (primer, primer_root, primer_attr)]
