@@ -157,6 +157,11 @@ int32_t amt_diff_subln_fwd(const float* o1, const float* o2, const float* w, flo
                            float lambda_full, float out_scale, float eps, void* stream);
 /* y = a + b over n floats (n % 4 == 0): the residual add of the pre-norm layers (custom_transformer.py:1241-1249). */
 int32_t amt_add_fwd(const float* a, const float* b, float* y, int64_t n, void* stream);
+/* y[r][:] = x[r][:] * row_scale[r] (+ add[r][:] when add != null): the video rows dropped by dropTokenRate in the V1 / V2 / V3
+ * classes (model/video_music_transformer.py:193-197, 488-492, 798-802: vf * (rand(B,S) > rate), also in eval mode), with the
+ * positional rows that follow (:208) as `add`.  dim a multiple of 4. */
+int32_t amt_row_scale_add_fwd(const float* x, const float* row_scale, const float* add, float* y, int32_t rows, int32_t dim,
+                              void* stream);
 /* RMSNorm(x + resid): the post-norm residual form of the custom layers (custom_transformer.py:1233-1240); resid may be null. */
 int32_t amt_rmsnorm_resid_fwd(const float* x, const float* resid, const float* w, float* y, int32_t rows, int32_t dim,
                               float eps, void* stream);

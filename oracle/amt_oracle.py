@@ -323,9 +323,10 @@ def v2_ff(x, sd, prefix):
     return moe_forward(x, sub, n_exp, k=2, shared=True)
 
 
-def forward_v2(sd, H, x_root, x_attr, sem, key, scene_off, motion, emotion, max_seq_video=300):
+def forward_v2(sd, H, x_root, x_attr, sem, key, scene_off, motion, emotion, max_seq_video=300, mask=True, drop_keep=None):
     """VideoMusicTransformer_V2.forward, version '2.2', chord_embed=False (:427-516): no additive positional
-    encoding, RoPE inside every attention, post-norm layers (custom_transformer.py:1228-1240, 1260-1276)."""
+    encoding, RoPE inside every attention, post-norm layers (custom_transformer.py:1228-1240, 1260-1276).  ``mask=False``:
+    tgt_mask=None (:440-443).  ``drop_keep`` (B, S) in {0, 1}: the dropTokenRate mask ``torch.rand(B, S) > rate`` (:488-492)."""
     d = sd["Wout.weight"].shape[1]
     cache = rope_cache(d, max_seq_video).to(sd["Wout.weight"].dtype)
     x = sd["embedding_root.weight"][x_root] + sd["embedding_attr.weight"][x_attr]
@@ -339,6 +340,8 @@ def forward_v2(sd, H, x_root, x_attr, sem, key, scene_off, motion, emotion, max_
     vf = torch.cat([vf, motion.unsqueeze(-1).to(x.dtype) if motion.dim() == 2 else motion.to(x.dtype)], dim=-1)
     vf = torch.cat([vf, emotion.to(x.dtype)], dim=-1)
     vf = linear(vf, sd["Linear_vis.weight"], sd["Linear_vis.bias"])
+    if drop_keep is not None:
+        vf = vf * drop_keep.to(vf.dtype).unsqueeze(-1)
     xf, src = x.permute(1, 0, 2).contiguous(), vf.permute(1, 0, 2).contiguous()     # seq-first
     for i in range(n_layers_of(sd, "encoder")):
         p = f"transformer.encoder.layers.{i}."
@@ -348,7 +351,7 @@ def forward_v2(sd, H, x_root, x_attr, sem, key, scene_off, motion, emotion, max_
     t = xf
     for i in range(n_layers_of(sd, "decoder")):
         p = f"transformer.decoder.layers.{i}."
-        t = layer_norm(t + v2_attention(t, t, sd, p + "self_attn.", H, cache, True), sd[p + "norm1.weight"], sd[p + "norm1.bias"])
+        t = layer_norm(t + v2_attention(t, t, sd, p + "self_attn.", H, cache, mask is True), sd[p + "norm1.weight"], sd[p + "norm1.bias"])
         t = layer_norm(t + v2_attention(t, memory, sd, p + "cross_attn.", H, cache, False), sd[p + "norm2.weight"], sd[p + "norm2.bias"])
         t = layer_norm(t + v2_ff(t, sd, p + "ff."), sd[p + "norm3.weight"], sd[p + "norm3.bias"])
     t = layer_norm(t, sd["transformer.decoder.norm.weight"], sd["transformer.decoder.norm.bias"])

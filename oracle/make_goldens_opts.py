@@ -10,8 +10,9 @@ VERDICT r1 "missing" item 5; none of them has a caller in the reference, the fix
   * forward(mask=False) (:978-982): no causal mask; `_skew` (model/rpr.py:439-455) still zeroes the relative term above the diagonal.
   * IS_SEPERATED = True (utilities/constants.py:11, model/video_music_transformer.py:968-973,1036-1040): Wout_root / Wout_attr heads,
     forward returns a pair.  The module constant is switched on for the construction and the call, then restored.
-  * dropTokenRate of the V2 class (:332, 488-492): rows of the video stream zeroed by `torch.rand(B, S) > rate`, also in eval mode;
-    torch.manual_seed right before the call pins the mask.
+  * dropTokenRate of the V1 / V2 / V3 classes (:193-197, 488-492, 798-802): rows of the video stream zeroed by
+    `torch.rand(B, S) > rate`, also in eval mode and anew in every forward of a generate; torch.manual_seed before the call pins
+    the masks.  The same classes with mask=False and with the top-k branch (beam=2, beam_chance=0.5).
 -> tests/golden/g_opts.npz"""
 import os
 import random
@@ -104,21 +105,51 @@ def main():
     finally:
         ref.vmt.IS_SEPERATED = False
 
-    # ---- dropTokenRate (V2 '2.2') ----
-    cfg2 = dict(version_name="2.2", n_layers=2, num_heads=4, d_model=128, dim_feedforward=256, max_sequence_chord=300,
-                total_vf_dim=synthetic.total_vf_dim(1), dropTokenRate=0.3)
-    mv = ref.vmt.VideoMusicTransformer_V2(**cfg2).eval()
-    MG.load_synthetic(mv, seed=0)
+    # ---- the V1 / V2 / V3 classes: dropTokenRate, mask=False, the top-k branch ----
+    V4 = dict(n_layers=4, num_heads=4, d_model=128, dim_feedforward=256, max_sequence_chord=300, total_vf_dim=synthetic.total_vf_dim(1))
+    fam = (("v22", ref.vmt.VideoMusicTransformer_V2, dict(V4, version_name="2.2")),
+           ("v20", ref.vmt.VideoMusicTransformer_V2, dict(V4, version_name="2.0")),
+           ("v11", ref.vmt.VideoMusicTransformer_V1, dict(V4, version_name="1.1")),
+           ("v30", ref.vmt.VideoMusicTransformer_V3, dict(V4, version_name="3.0")))
     B, L = 2, 12
     rootv = rs.randint(0, 13, size=(B, L)).astype(np.int64)
     attrv = rs.randint(0, 14, size=(B, L)).astype(np.int64)
-    torch.manual_seed(5)
-    y = mv(t(rootv), t(rootv), t(attrv), t(feats["semantic"][:B]), t(key[:B]), t(feats["scene_offset"][:B]),
-           t(feats["motion"][:B]), t(feats["emotion"][:B]))
-    torch.manual_seed(5)
-    out["drop_mask"] = (torch.rand(B, feats["semantic"].shape[1]) > 0.3).numpy()
-    out["drop_root"], out["drop_attr"], out["drop_logits"] = rootv, attrv, y.numpy()
-    print("dropTokenRate kept rows", int(out["drop_mask"].sum()), "of", out["drop_mask"].size, flush=True)
+    out["fam_root"], out["fam_attr"] = rootv, attrv
+    fargs = (t(rootv), t(rootv), t(attrv), t(feats["semantic"][:B]), t(key[:B]), t(feats["scene_offset"][:B]), t(feats["motion"][:B]),
+             t(feats["emotion"][:B]))
+    gkw = dict(feature_semantic_list=t(feats["semantic"][:1]), feature_key=t(key[0]), feature_scene_offset=t(feats["scene_offset"][:1]),
+               feature_motion=t(feats["motion"][:1]), feature_emotion=t(feats["emotion"][:1]),
+               primer=torch.tensor([1]), primer_root=torch.tensor([1]), primer_attr=torch.tensor([0]))
+    for tag, cls, c in fam:
+        mv = cls(dropTokenRate=0.3, **c).eval()
+        MG.load_synthetic(mv, seed=0)
+        torch.manual_seed(5)
+        out[f"{tag}_drop_logits"] = mv(*fargs).numpy()
+        torch.manual_seed(5)
+        out[f"{tag}_drop_mask"] = (torch.rand(B, feats["semantic"].shape[1]) > 0.3).numpy()
+        # generate: one fresh mask per step's forward
+        gaps.clear()
+        Categorical.sample = argmax_sample
+        try:
+            torch.manual_seed(9)
+            out[f"{tag}_drop_g2"] = mv.generate(beam=0, target_seq_length=14, **gkw).numpy()
+        finally:
+            Categorical.sample = orig
+        out[f"{tag}_drop_g2_min_gap"] = np.array(min(gaps))
+        print(tag, "dropTokenRate: kept", int(out[f"{tag}_drop_mask"].sum()), "of", out[f"{tag}_drop_mask"].size, "G2 min rel gap", min(gaps), flush=True)
+        mv.dropTokenRate = 0.0
+        out[f"{tag}_nomask_logits"] = mv(*fargs, mask=False).numpy()
+        gaps.clear()
+        torch.topk = topk_spy
+        Categorical.sample = argmax_sample
+        try:
+            random.seed(13)
+            out[f"{tag}_beam2_c05"] = mv.generate(beam=2, beam_chance=0.5, target_seq_length=24, **gkw).numpy()
+        finally:
+            torch.topk = orig_topk
+            Categorical.sample = orig
+        out[f"{tag}_beam2_c05_min_gap"] = np.array(min(gaps))
+        print(tag, "beam2/0.5", out[f"{tag}_beam2_c05"].shape, "min rel gap", min(gaps), flush=True)
     np.savez_compressed(os.path.join(MG.OUT, "g_opts.npz"), **out)
     print("wrote g_opts.npz")
 

@@ -311,3 +311,17 @@ def test_separated_heads(golden):
     yr, ya = O.forward(sd, 4, torch.from_numpy(g["sep_root"]), torch.from_numpy(g["sep_attr"]), f["semantic"], f["key"], f["scene_offset"],
                        f["motion"], f["emotion"], separated=True)
     assert np.abs(yr.numpy() - g["sep_y_root"]).max() < TOL and np.abs(ya.numpy() - g["sep_y_attr"]).max() < TOL
+
+
+def test_v2_drop_token_rate_and_no_mask(golden):
+    """VideoMusicTransformer_V2('2.2', 4 layers) with dropTokenRate=0.3 under torch.manual_seed(5), and with mask=False."""
+    from tests.helpers import CFG_V2, synthetic_sd_v2
+    g = golden("g_opts.npz")
+    sd = synthetic_sd_v2(dict(CFG_V2, n_layers=4))
+    f = feats_t(synthetic.synthetic_features(3, seed=1234), slice(0, 2), key=g["key"])
+    args = (sd, 4, torch.from_numpy(g["fam_root"]), torch.from_numpy(g["fam_attr"]), f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"])
+    torch.manual_seed(5)
+    keep = torch.rand(2, f["semantic"].shape[1]) > 0.3
+    assert np.array_equal(keep.numpy(), g["v22_drop_mask"])
+    assert np.abs(O.forward_v2(*args, drop_keep=keep).numpy() - g["v22_drop_logits"]).max() < 1e-4       # fp32, logits of magnitude ~20
+    assert np.abs(O.forward_v2(*args, mask=False).numpy() - g["v22_nomask_logits"]).max() < 1e-4

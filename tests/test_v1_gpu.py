@@ -129,3 +129,9 @@ def test_lockstep_generate_batch_equals_per_clip_generate(make, B, P):
         one = [a[:1] for a in args]
         assert torch.equal(m.generate_batch(*one, pr[0][0], pr[1][0], pr[2][0], target_seq_length=T, beam=0, sampler="argmax"),
                            m.generate_batch(*one, pr[0][0], pr[1][0], pr[2][0], target_seq_length=T, beam=0, sampler="argmax", decision="host"))
+
+
+def test_v1_options_vs_reference_golden(golden):
+    """dropTokenRate, forward(mask=False), beam=2 / beam_chance=0.5 of the reference V1 class ('1.1') -- tests/golden/g_opts.npz."""
+    from tests.test_v2_gpu import check_family_options
+    check_family_options(golden, "v11", build("1.1"), lambda **over: build("1.1", **over))

@@ -165,8 +165,6 @@ def test_v2_chord_table_rows_follow_the_state_dict():
 def test_v2_unbuilt_variants_say_so():
     with pytest.raises(NotImplementedError):
         VideoMusicTransformer_V2(**dict(CFG_V2, version_name="2.3"))
-    with pytest.raises(NotImplementedError):
-        VideoMusicTransformer_V2(**dict(CFG_V2, dropTokenRate=0.1))
 
 
 @pytest.mark.parametrize("clip", [0, 1])
@@ -200,3 +198,51 @@ def test_v2_well_conditioned_generate_vs_reference_golden(golden, clip):
             root, attr = torch.from_numpy(g["fwd_root"]), torch.from_numpy(g["fwd_attr"])
             y = m(root, root, attr, f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"])
             assert np.abs(y.cpu().numpy() - g["fwd_logits"]).max() < 1e-3
+
+
+# ---------------- rarely used options (tests/golden/g_opts.npz, oracle/make_goldens_opts.py; VERDICT r1 missing #5) ----------------
+
+def check_family_options(golden, tag, m, mid):
+    """dropTokenRate (forward under torch.manual_seed(5), generate under torch.manual_seed(9): a fresh mask per step), forward
+    (mask=False), generate(beam=2, beam_chance=0.5) with python's `random` seeded -- against the reference class's own outputs."""
+    import random
+    g = golden("g_opts.npz")
+    key = g["key"]
+    feats = synthetic.synthetic_features(3, seed=1234)
+    f = {k: v.cuda() for k, v in feats_t(feats, slice(0, 2), key=key).items()}
+    root, attr = torch.from_numpy(g["fam_root"]), torch.from_numpy(g["fam_attr"])
+    f1 = {k: v.cuda() for k, v in feats_t(feats, slice(0, 1), key=key).items()}
+    gkw = dict(feature_semantic_list=f1["semantic"], feature_key=f1["key"][0], feature_scene_offset=f1["scene_offset"], feature_motion=f1["motion"],
+               feature_emotion=f1["emotion"], primer=torch.tensor([1]), primer_root=torch.tensor([1]), primer_attr=torch.tensor([0]))
+    with torch.no_grad():
+        y = m(root, root, attr, f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], mask=False)
+        assert np.abs(y.cpu().numpy() - g[f"{tag}_nomask_logits"]).max() < 1e-3
+        random.seed(13)
+        ids = m.generate(beam=2, beam_chance=0.5, target_seq_length=24, sampler="argmax", **gkw)
+        assert ids.shape == (2, 24) and np.array_equal(ids.cpu().numpy(), g[f"{tag}_beam2_c05"])
+        random.seed(13)
+        rows = m.generate_batch(f1["semantic"], f1["key"], f1["scene_offset"], f1["motion"], f1["emotion"], torch.tensor([1]), torch.tensor([1]),
+                                torch.tensor([0]), target_seq_length=24, beam=2, beam_chance=0.5, sampler="argmax")
+        assert np.array_equal(rows.cpu().numpy(), g[f"{tag}_beam2_c05"][:1])
+        md = mid(dropTokenRate=0.3)
+        torch.manual_seed(5)
+        y = md(root, root, attr, f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"])
+        assert np.abs(y.cpu().numpy() - g[f"{tag}_drop_logits"]).max() < 1e-3
+        torch.manual_seed(9)
+        ids = md.generate(beam=0, target_seq_length=14, sampler="argmax", **gkw)
+        assert np.array_equal(ids.cpu().numpy(), g[f"{tag}_drop_g2"])
+        torch.manual_seed(9)
+        rows = md.generate_batch(f1["semantic"], f1["key"], f1["scene_offset"], f1["motion"], f1["emotion"], torch.tensor([1]), torch.tensor([1]),
+                                 torch.tensor([0]), target_seq_length=14, beam=0, sampler="argmax")
+        assert np.array_equal(rows.cpu().numpy(), g[f"{tag}_drop_g2"])
+
+
+@pytest.mark.parametrize("tag,version", [("v22", "2.2"), ("v20", "2.0")])
+def test_v2_options_vs_reference_golden(golden, tag, version):
+    def mid(**over):
+        cfg = dict(CFG_V2, version_name=version, n_layers=4, **over)
+        m = VideoMusicTransformer_V2(**cfg).eval()
+        shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=0).items()})
+        return m.cuda()
+    check_family_options(golden, tag, mid(), mid)

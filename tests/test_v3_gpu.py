@@ -88,3 +88,9 @@ def test_v3_generate_batch_equals_per_clip_generate(version, B, P):
                 one = m.generate(f["semantic"][c:c + 1], f["key"][c], f["scene_offset"][c:c + 1], f["motion"][c:c + 1], f["emotion"][c:c + 1],
                                  pr[0][c], pr[1][c], pr[2][c], target_seq_length=T, **kw)
                 assert torch.equal(one[0], got[c]), (kw, c)
+
+
+def test_v3_options_vs_reference_golden(golden):
+    """dropTokenRate, forward(mask=False), beam=2 / beam_chance=0.5 of the reference V3 class ('3.0') -- tests/golden/g_opts.npz."""
+    from tests.test_v2_gpu import check_family_options
+    check_family_options(golden, "v30", build("3.0"), lambda **over: build("3.0", **over))

@@ -55,6 +55,7 @@ SIGNATURES = {
     "amt_rmsnorm_resid_fwd": [_P, _P, _P, _P, _I, _I, _F, _P],
     "amt_diff_subln_fwd": [_P, _P, _P, _P, _I, _I, _F, _F, _F, _P],
     "amt_add_fwd": [_P, _P, _P, C.c_int64, _P],
+    "amt_row_scale_add_fwd": [_P, _P, _P, _P, _I, _I, _P],
     "amt_rope_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "amt_rpr_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "amt_rpr_attn_nomask_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

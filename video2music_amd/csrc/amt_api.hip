@@ -998,6 +998,12 @@ extern "C" int32_t amt_diff_subln_fwd(const float* o1, const float* o2, const fl
     return amt_launch_diff_subln(o1, o2, w, y, rows, hd, lambda_full, out_scale, eps, (hipStream_t)stream);
 }
 
+extern "C" int32_t amt_row_scale_add_fwd(const float* x, const float* row_scale, const float* add, float* y, int32_t rows, int32_t dim,
+                                         void* stream) {
+    AMT_CHECK_ARG(x && row_scale && y, "amt_row_scale_add_fwd: null pointer");
+    return amt_launch_row_scale_add(x, row_scale, add, y, rows, dim, (hipStream_t)stream);
+}
+
 extern "C" int32_t amt_add_fwd(const float* a, const float* b, float* y, int64_t n, void* stream) {
     AMT_CHECK_ARG(a && b && y, "amt_add_fwd: null pointer");
     return amt_launch_add(a, b, y, (long)n, (hipStream_t)stream);

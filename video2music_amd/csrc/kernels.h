@@ -43,6 +43,7 @@ int32_t amt_launch_rmsnorm(const float* x, const float* w, float* y, int rows, i
 int32_t amt_launch_diff_subln(const float* o1, const float* o2, const float* w, float* y, int rows, int hd, float lambda,
                               float out_scale, float eps, hipStream_t stream);
 int32_t amt_launch_add(const float* a, const float* b, float* y, long n, hipStream_t stream);
+int32_t amt_launch_row_scale_add(const float* x, const float* row_scale, const float* add, float* y, int rows, int dim, hipStream_t stream);
 // rotary embedding on interleaved pairs: x viewed as [n0][seq][n2][hd], cache [>=seq][cache_half][2];
 // reproduces the reference's view(-1, seq, 1, hd/2, 2)[:n0] reinterpretation of the cache
 int32_t amt_launch_rope(const float* x, const float* cache, float* y, int n0, int seq, int n2, int hd,

@@ -192,7 +192,28 @@ __global__ void add_kernel(const float* __restrict__ a, const float* __restrict_
     }
 }
 
+// y[r][:] = x[r][:] * row_scale[r] (+ add[r][:]): the dropped video rows of the V1/V2/V3 classes (dropTokenRate)
+__global__ void row_scale_add_kernel(const float* __restrict__ x, const float* __restrict__ row_scale, const float* __restrict__ add,
+                                     float* __restrict__ y, long n4, int dim4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) {
+        const float m = row_scale[i / dim4];
+        const float4 u = ld4(x + 4 * i);
+        float4 v = make_float4(u.x * m, u.y * m, u.z * m, u.w * m);
+        if (add) { const float4 a = ld4(add + 4 * i); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+        st4(y + 4 * i, v);
+    }
+}
+
 }  // namespace
+
+int32_t amt_launch_row_scale_add(const float* x, const float* row_scale, const float* add, float* y, int rows, int dim, hipStream_t stream) {
+    AMT_CHECK_ARG(rows > 0 && dim > 0 && dim % 4 == 0, "row_scale_add: bad shape rows=%d dim=%d", rows, dim);
+    const long n4 = (long)rows * (dim / 4);
+    hipLaunchKernelGGL(row_scale_add_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, row_scale, add, y, n4, dim / 4);
+    AMT_LAUNCH_CHECK();
+    return 0;
+}
 
 int32_t amt_launch_diff_subln(const float* o1, const float* o2, const float* w, float* y, int rows, int hd, float lambda,
                               float out_scale, float eps, hipStream_t stream) {

@@ -578,8 +578,6 @@ class VideoMusicTransformer_V2(nn.Module):
         self._use_rope = (not self._learned_pos) and version_name in ("2.1", "2.2", "2.3")
         if version_name in "2.3":
             raise NotImplementedError("version '2.3' swaps the experts for efficient_kan.KANLinear, a package the reference does not vendor")
-        if dropTokenRate != 0.0:
-            raise NotImplementedError("dropTokenRate (a random mask applied even in eval, :484-488) is outside this path")
         # rms_norm is accepted and has no effect, as in the reference (its RMSNorm branch is commented out, :364-371);
         # '2.1' differs from '2.2' by a top-k scheduler that only acts in training (moe.py:232-236)
         if n_layers < 3:
@@ -747,7 +745,21 @@ class VideoMusicTransformer_V2(nn.Module):
         if self.scene_embed:                                    # + scene_embedding(feature_scene_offset.int()) (:481-484)
             srows = self.scene_embedding.weight.detach()[scene.to(torch.int32).long()].reshape(B * S, d).contiguous()
             pos_rows = srows if pos_rows is None else ops.add(pos_rows, srows)
-        vf = ops.linear(ops.concat_features(sem, scene, motion, emotion, Fpad), Wv, self.Linear_vis.bias.detach(), resid=pos_rows)
+        if self.dropTokenRate != 0.0:
+            # Drop Tokens (:193-197, 488-492, 798-802): rows of (Linear_vis(.) + scene rows) zeroed by a fresh
+            # `torch.rand(B, S) > rate` in EVERY forward, eval mode included; the positional rows come after it.  The draw is the
+            # reference's own call (default CPU generator), so torch.manual_seed pins the same mask in both implementations.
+            keep = (torch.rand(B, S) > self.dropTokenRate).float().to(dev).reshape(B * S).contiguous()
+            srows = None
+            if self.scene_embed:
+                srows = self.scene_embedding.weight.detach()[scene.to(torch.int32).long()].reshape(B * S, d).contiguous()
+            lp = None
+            if self._learned_pos:
+                lp = self.positional_embedding_video.weight.detach()[:S].unsqueeze(0).expand(B, S, d).contiguous().view(B * S, d)
+            vf = ops.linear(ops.concat_features(sem, scene, motion, emotion, Fpad), Wv, self.Linear_vis.bias.detach(), resid=srows)
+            vf = ops.row_scale_add(vf, keep, lp)
+        else:
+            vf = ops.linear(ops.concat_features(sem, scene, motion, emotion, Fpad), Wv, self.Linear_vis.bias.detach(), resid=pos_rows)
         src = vf if clips else vf.view(B, S, d).permute(1, 0, 2).contiguous().view(S * B, d)
         self._clip_rows = bool(clips)
         try:
@@ -762,13 +774,13 @@ class VideoMusicTransformer_V2(nn.Module):
         src = self._ln(self._attention(src, src, lyr.self_attn, S, S, B, False, src), lyr.norm1)
         return self._ln(self._ff(src, lyr.ff, S, B), lyr.norm2, resid=src)
 
-    def _dec_layer(self, t, memory, lyr, L, S, B):
+    def _dec_layer(self, t, memory, lyr, L, S, B, causal=True):
         """Post-norm decoder layer (custom_transformer.py:1262-1276)."""
-        t = self._ln(self._attention(t, t, lyr.self_attn, L, L, B, True, t), lyr.norm1)
+        t = self._ln(self._attention(t, t, lyr.self_attn, L, L, B, causal, t), lyr.norm1)
         t = self._ln(self._attention(t, memory, lyr.cross_attn, L, S, B, False, t), lyr.norm2)
         return self._ln(self._ff(t, lyr.ff, L, B), lyr.norm3, resid=t)
 
-    def _decode(self, x_root, x_attr, feature_key, memory, B, S, clips=False):
+    def _decode(self, x_root, x_attr, feature_key, memory, B, S, clips=False, causal=True):
         """Chord stream + decoder stack + Wout (:437-452, :490-516) over a precomputed encoder memory.  clips=True: the B
         rows are independent clips (each computed as a batch of one), `memory` clip-major as `_encode_memory(clips=True)`
         returns it."""
@@ -785,7 +797,7 @@ class VideoMusicTransformer_V2(nn.Module):
         self._clip_rows = bool(clips)
         try:
             for lyr in self.transformer.decoder.layers:
-                t = self._dec_layer(t, memory, lyr, L, S, B)
+                t = self._dec_layer(t, memory, lyr, L, S, B, causal)
         finally:
             self._clip_rows = False
         t = self._ln(t, self.transformer.decoder.norm)
@@ -1008,13 +1020,25 @@ class VideoMusicTransformer_V2(nn.Module):
 
     def forward(self, x, x_root, x_attr, feature_semantic_list, feature_key, feature_scene_offset, feature_motion,
                 feature_emotion, mask=True):
-        if mask is not True:
-            raise NotImplementedError("forward(mask=False) is not used by any reference caller")
         memory, B, S = self._encode_memory(feature_semantic_list, feature_scene_offset, feature_motion, feature_emotion)
         assert x_root.shape[0] == B, f"{x_root.shape[0]} chord sequences but {B} clips of video features"
         if self.chord_embed:                     # the chord ids themselves index the frozen table (:431-432)
             x_root, x_attr = x, torch.zeros_like(x)
-        return self._decode(x_root, x_attr, feature_key, memory, B, S)
+        # mask other than True: tgt_mask=None (:440-443), the decoder self-attention sees every position
+        return self._decode(x_root, x_attr, feature_key, memory, B, S, causal=mask is True)
+
+    def _generate_clip_by_clip(self, sem, key, scene, motion, emotion, primer, primer_root, primer_attr, **kw):
+        """The options whose reference semantics are per call and host-side (top-k branch with beam > 1 or beam_chance < 1:
+        python's `random` per step; dropTokenRate: a fresh torch.rand mask per forward): the clips run one after the other
+        through `generate`, in order, and row 0 of each result (the top-1 row) is returned."""
+        nb = sem.shape[0]
+        prim = [torch.as_tensor(q).long().cpu() for q in (primer, primer_root, primer_attr)]
+        prim = [q.unsqueeze(0).expand(nb, -1) if q.dim() == 1 else q for q in prim]
+        k = key.reshape(-1)
+        k = k.expand(nb) if k.numel() == 1 else k
+        rows = [self.generate(sem[c:c + 1], k[c:c + 1], scene[c:c + 1], motion[c:c + 1], emotion[c:c + 1], prim[0][c], prim[1][c],
+                              prim[2][c], decision="host", **kw)[:1] for c in range(nb)]
+        return torch.cat(rows, dim=0)
 
     def _step_batch(self, st, keys, state):
         _lib.call("amt_v2_step_batch", st["tab"], self.nlayers, self.nhead, self.d_model, st["dff"], self.n_experts, st["S"],
@@ -1038,8 +1062,11 @@ class VideoMusicTransformer_V2(nn.Module):
         keeps the round-1 loop (logits copied to the host every step, torch's own Categorical)."""
         from ..utilities.constants import chord_to_root_attr
         assert (not self.training), "Cannot generate while in training mode"
-        if beam not in (0, 1):
-            raise NotImplementedError("beam > 1 is not implemented (generate.py:347-349 asserts it out as well)")
+        if beam > 1 or (beam == 1 and beam_chance < 1.0) or self.dropTokenRate != 0.0:
+            return self._generate_clip_by_clip(feature_semantic_list, feature_key, feature_scene_offset, feature_motion, feature_emotion,
+                                               primer, primer_root, primer_attr, target_seq_length=target_seq_length, beam=beam,
+                                               beam_chance=beam_chance, max_conseq_N=max_conseq_N, max_conseq_chord=max_conseq_chord,
+                                               temperature=temperature, sampler=sampler)
         dev = self.Wout.weight.device
         T = int(target_seq_length)
         if T > self._max_dec:
@@ -1182,12 +1209,18 @@ class VideoMusicTransformer_V2(nn.Module):
         does not tolerate the other threads' synchronisations)."""
         from ..utilities.constants import chord_to_root_attr
         assert (not self.training), "Cannot generate while in training mode"
-        if beam not in (0, 1):
-            raise NotImplementedError("beam > 1 is not implemented (generate.py:347-349 asserts it out as well)")
+        import random
         print("Generating sequence of max length:", target_seq_length)
         if decision not in ("device", "host"):
             raise ValueError(f"unknown decision {decision!r}")
-        if decision == "device" and use_cache and use_graph and sampler in ("categorical", "argmax"):
+        mixed = beam > 1 or (beam == 1 and beam_chance < 1.0)      # the top-k branch as written (:551-561): host loop, (beam, T) rows
+        if self.chord_embed and beam > 1:
+            raise RuntimeError("chord_embed with beam > 1 feeds `beam` chord rows against one clip of video features: the "
+                               "reference fails in the cross-attention at the second step")
+        redraw = self.dropTokenRate != 0.0     # every reference step is a full forward with a fresh drop mask (:488-492)
+        if redraw:
+            use_cache = False
+        if decision == "device" and use_cache and use_graph and sampler in ("categorical", "argmax") and not mixed:
             return self.generate_batch(feature_semantic_list, feature_key, feature_scene_offset, feature_motion, feature_emotion,
                                        primer, primer_root, primer_attr, target_seq_length=target_seq_length, beam=beam,
                                        beam_chance=beam_chance, max_conseq_N=max_conseq_N, max_conseq_chord=max_conseq_chord,
@@ -1233,10 +1266,15 @@ class VideoMusicTransformer_V2(nn.Module):
                     step(cur - 1)
                 row = st["logits"].cpu()
             else:
+                if redraw and cur > P:
+                    memory, B, S = self._encode_memory(feature_semantic_list, feature_scene_offset, feature_motion, feature_emotion)
                 row = self._decode(gen_root[:, :cur], gen_attr[:, :cur], feature_key, memory, B, S)[0, cur - 1].cpu()
             probs = torch.softmax(row / temperature, dim=-1)[:CHORD_END]
-            if beam == 1:
-                gen[0, cur] = int(torch.topk(probs, 1)[1][0])
+            beam_ran = 2.0 if beam == 0 else random.uniform(0, 1)
+            if beam_ran <= beam_chance:
+                top_i = torch.topk(probs, beam)[1]          # (:556-561): `beam` copies of row 0, the k best ids in column cur
+                gen = gen[top_i // CHORD_SIZE, :]
+                gen[..., cur] = top_i % CHORD_SIZE
                 if self.chord_embed:        # the ids are the model input here, so the top-1 choice does feed back
                     gen_root[0, cur] = gen[0, cur]
             else:
@@ -1248,7 +1286,7 @@ class VideoMusicTransformer_V2(nn.Module):
                     tok = int((probs / probs.sum()).argmax())
                 else:
                     tok = int(torch.distributions.categorical.Categorical(probs=probs).sample())
-                gen[0, cur] = tok
+                gen[:, cur] = tok
                 gen_root[0, cur], gen_attr[0, cur] = (tok, 0) if self.chord_embed else chord_to_root_attr(tok)
             cur += 1
         return gen[:, :cur].to(dev)
@@ -1272,8 +1310,6 @@ class VideoMusicTransformer_V1(VideoMusicTransformer_V2):
                  max_sequence_midi=2048, max_sequence_video=300, max_sequence_chord=300, total_vf_dim=0, rms_norm=False,
                  scene_embed=False, chord_embed=False, dropTokenRate=0.0):
         nn.Module.__init__(self)
-        if dropTokenRate != 0.0:
-            raise NotImplementedError("dropTokenRate (a random mask applied even in eval, :191-196) is outside this path")
         from .custom_transformer import RMSNorm
         from .moe import GLUExpert, MoELayer, SharedMoELayer, SiLUExpert
         shallow = version_name in ("1.3.3", "1.3.4")
@@ -1382,8 +1418,6 @@ class VideoMusicTransformer_V3(VideoMusicTransformer_V2):
         nn.Module.__init__(self)
         if version_name not in ("3.0", "3.1", "3.2"):
             raise ValueError("the reference builds an encoder for '3.0', '3.1' and '3.2' only (:672-690)")
-        if dropTokenRate != 0.0:
-            raise NotImplementedError("dropTokenRate (a random mask applied even in eval) is outside this path")
         if n_layers < 3:
             raise ValueError("the reference builds 3 shallow + (n_layers-3) deep layers")
         from .custom_transformer import RMSNorm
@@ -1463,12 +1497,12 @@ class VideoMusicTransformer_V3(VideoMusicTransformer_V2):
         src = self._attention(h, h, lyr.self_attn, S, S, B, False, src)
         return ops.add(src, self._ff(self._ln(src, lyr.norm2), lyr.ff, S, B))
 
-    def _dec_layer(self, t, memory, lyr, L, S, B):
+    def _dec_layer(self, t, memory, lyr, L, S, B, causal=True):
         if not self.pre_norm:
-            return super()._dec_layer(t, memory, lyr, L, S, B)
+            return super()._dec_layer(t, memory, lyr, L, S, B, causal)
         from .. import ops
         h = self._ln(t, lyr.norm1)                                                   # pre-norm (:1277-1292)
-        t = self._attention(h, h, lyr.self_attn, L, L, B, True, t)
+        t = self._attention(h, h, lyr.self_attn, L, L, B, causal, t)
         t = self._attention(self._ln(t, lyr.norm2), memory, lyr.cross_attn, L, S, B, False, t)
         return ops.add(t, self._ff(self._ln(t, lyr.norm3), lyr.ff, L, B))
 
@@ -1480,8 +1514,11 @@ class VideoMusicTransformer_V3(VideoMusicTransformer_V2):
         as a batch of one (clip-major rows; the reference's raw views are then the B = 1 ones)."""
         from ..utilities.constants import chord_to_root_attr
         assert (not self.training), "Cannot generate while in training mode"
-        if beam not in (0, 1):
-            raise NotImplementedError("beam > 1 is not implemented (generate.py:347-349 asserts it out as well)")
+        if beam > 1 or (beam == 1 and beam_chance < 1.0) or self.dropTokenRate != 0.0:
+            return self._generate_clip_by_clip(feature_semantic_list, feature_key, feature_scene_offset, feature_motion, feature_emotion,
+                                               primer, primer_root, primer_attr, target_seq_length=target_seq_length, beam=beam,
+                                               beam_chance=beam_chance, max_conseq_N=max_conseq_N, max_conseq_chord=max_conseq_chord,
+                                               temperature=temperature, sampler=sampler)
         dev = self.Wout.weight.device
         T = int(target_seq_length)
         if T > self._max_dec:

@@ -47,6 +47,14 @@ def add(a, b):
     return y
 
 
+def row_scale_add(x, row_scale, add=None):
+    """x * row_scale[:, None] (+ add): the dropTokenRate mask of the V1 / V2 / V3 video stream."""
+    rows, dim = x.shape
+    y = torch.empty_like(x)
+    _lib.call("amt_row_scale_add_fwd", p(x), p(row_scale), p(add), p(y), rows, dim, _st())
+    return y
+
+
 def rmsnorm(x, w, resid=None, eps=1e-6):
     """RMSNorm(x (+ resid)) * w (custom_transformer.py:27-45)."""
     rows, dim = x.shape
