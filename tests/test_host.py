@@ -185,3 +185,16 @@ def test_moe_schedulers_follow_the_reference_or_refuse():
     assert b.topk_scheduler is sched
     with pytest.raises(NotImplementedError, match="temperature"):
         SharedMoELayer(GLUExpert(16, 32), 16, temperature_scheduler=sched)
+
+
+def test_v2_builds_three_shallow_layers_whatever_n_layers_says():
+    """model/video_music_transformer.py:411-416 of the reference: `rate = 3` shallow layers + (n_layers - 3) deep ones, so n_layers = 2
+    still gives three (117 state_dict entries for this configuration, counted on the reference class)."""
+    from video2music_amd import synthetic
+    from video2music_amd.model.video_music_transformer import VideoMusicTransformer_V2, VideoMusicTransformer_V3
+    m = VideoMusicTransformer_V2(version_name="2.2", n_layers=2, num_heads=4, d_model=128, dim_feedforward=256, max_sequence_chord=300,
+                                 total_vf_dim=synthetic.total_vf_dim(1))
+    assert len(m.transformer.decoder.layers) == 3 and len(m.transformer.encoder.layers) == 3 and len(m.state_dict()) == 117
+    with pytest.raises(IndexError):
+        VideoMusicTransformer_V3(version_name="3.1", n_layers=2, num_heads=4, d_model=128, dim_feedforward=256,
+                                 total_vf_dim=synthetic.total_vf_dim(1))

@@ -580,8 +580,6 @@ class VideoMusicTransformer_V2(nn.Module):
             raise NotImplementedError("version '2.3' swaps the experts for efficient_kan.KANLinear, a package the reference does not vendor")
         # rms_norm is accepted and has no effect, as in the reference (its RMSNorm branch is commented out, :364-371);
         # '2.1' differs from '2.2' by a top-k scheduler that only acts in training (moe.py:232-236)
-        if n_layers < 3:
-            raise ValueError("the reference builds 3 shallow + (n_layers-3) deep layers")
         self.nlayers, self.nhead, self.d_model, self.d_ff, self.dropout = n_layers, num_heads, d_model, dim_feedforward, dropout
         self.max_seq_midi, self.max_seq_video, self.max_seq_chord = max_sequence_midi, max_sequence_video, max_sequence_chord
         self.scene_embed, self.chord_embed, self.dropTokenRate, self.version_name = scene_embed, chord_embed, dropTokenRate, version_name
@@ -612,7 +610,8 @@ class VideoMusicTransformer_V2(nn.Module):
             return SharedMoELayer(GLUExpert(d_model, dim_feedforward, dropout), d_model, n_experts=self.n_experts,
                                   n_experts_per_token=2, dropout=dropout, balancing=balancing)
 
-        self.transformer = _TransformerParamsV2(d_model, num_heads, n_layers, ff)
+        # three shallow layers whatever n_layers says, then n_layers - 3 deep ones (:411-416): n_layers < 3 still builds three
+        self.transformer = _TransformerParamsV2(d_model, num_heads, max(3, n_layers), ff)
         self.Wout = nn.Linear(d_model, CHORD_SIZE)
         self.softmax = nn.Softmax(dim=-1)
         if self._use_rope:
@@ -958,7 +957,7 @@ class VideoMusicTransformer_V2(nn.Module):
     def _decode_step_native(self, root, attr, key, t, st, state=None):
         """`_decode_step` issued by one library call (amt_v2_step): logits (159,) for input position t.  With `state`
         (int32 device tensor {position, root, attr}) the step reads those from device memory and increments the position."""
-        _lib.call("amt_v2_step", st["tab"], self.nlayers, self.nhead, self.d_model, st["dff"], self.n_experts, st["S"],
+        _lib.call("amt_v2_step", st["tab"], len(self.transformer.decoder.layers), self.nhead, self.d_model, st["dff"], self.n_experts, st["S"],
                   self._max_dec, int(t), int(root), int(attr), float(key), _lib.ptr(state), _lib.ptr(st["logits"]),
                   _lib.ptr(st["ws"]), _lib.stream_ptr())
         return st["logits"]
@@ -1041,7 +1040,7 @@ class VideoMusicTransformer_V2(nn.Module):
         return torch.cat(rows, dim=0)
 
     def _step_batch(self, st, keys, state):
-        _lib.call("amt_v2_step_batch", st["tab"], self.nlayers, self.nhead, self.d_model, st["dff"], self.n_experts, st["S"],
+        _lib.call("amt_v2_step_batch", st["tab"], len(self.transformer.decoder.layers), self.nhead, self.d_model, st["dff"], self.n_experts, st["S"],
                   self._max_dec, st["B"], _lib.ptr(keys), _lib.ptr(state), _lib.ptr(st["logits"]), _lib.ptr(st["ws"]), _lib.stream_ptr())
 
     def generate_batch(self, feature_semantic_list, feature_key, feature_scene_offset, feature_motion, feature_emotion,
@@ -1313,8 +1312,6 @@ class VideoMusicTransformer_V1(VideoMusicTransformer_V2):
         from .custom_transformer import RMSNorm
         from .moe import GLUExpert, MoELayer, SharedMoELayer, SiLUExpert
         shallow = version_name in ("1.3.3", "1.3.4")
-        if shallow and n_layers < 3:
-            raise ValueError("the reference builds 3 shallow + (n_layers-3) deep layers")
         self.nlayers, self.nhead, self.d_model, self.d_ff, self.dropout = n_layers, num_heads, d_model, dim_feedforward, dropout
         self.max_seq_midi, self.max_seq_video, self.max_seq_chord = max_sequence_midi, max_sequence_video, max_sequence_chord
         self.scene_embed, self.chord_embed, self.dropTokenRate, self.version_name = scene_embed, chord_embed, dropTokenRate, version_name
@@ -1350,7 +1347,8 @@ class VideoMusicTransformer_V1(VideoMusicTransformer_V2):
             return SharedMoELayer(expert(), d_model, n_experts=self.n_experts, n_experts_per_token=self.n_experts_per_token,
                                   balancing=False, dropout=dropout)
 
-        self.transformer = _TransformerParamsV2(d_model, num_heads, n_layers, ff, norm=RMSNorm if rms_norm else nn.LayerNorm)
+        self.transformer = _TransformerParamsV2(d_model, num_heads, max(3, n_layers) if shallow else n_layers, ff,      # (:114-119)
+                                                norm=RMSNorm if rms_norm else nn.LayerNorm)
         self.Wout = nn.Linear(d_model, CHORD_SIZE)
         self.softmax = nn.Softmax(dim=-1)
         if self._use_rope:
@@ -1419,7 +1417,7 @@ class VideoMusicTransformer_V3(VideoMusicTransformer_V2):
         if version_name not in ("3.0", "3.1", "3.2"):
             raise ValueError("the reference builds an encoder for '3.0', '3.1' and '3.2' only (:672-690)")
         if n_layers < 3:
-            raise ValueError("the reference builds 3 shallow + (n_layers-3) deep layers")
+            raise IndexError("list index out of range (the reference indexes its n_layers attention modules 0..2, :703-727)")
         from .custom_transformer import RMSNorm
         from .moe import GLUExpert, SharedMoELayer
         from .rotate_operation import RotaryPositionalEmbeddings
