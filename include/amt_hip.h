@@ -309,6 +309,18 @@ int32_t amt_v2_step_batch(const void* const* tab, int32_t n_layers, int32_t H, i
 int32_t amt_v2_decide_batch(const float* logits, int32_t ld_logits, int32_t* state_dev, int64_t* tokens, int64_t* roots,
                             int64_t* attrs, int32_t B, int32_t T, int32_t n_primer, int32_t beam, int32_t max_conseq_N,
                             int32_t max_conseq_chord, float temperature, const float* uniforms, int32_t chord_embed, void* stream);
+/* amt_v2_step_batch and the decision as ONE launch chain (what the lockstep generate replays T-2 times from a captured graph):
+ * the step for the position in state_dev[0] WITHOUT its trailing position increment, then one kernel that decides position
+ * state_dev[0] + 1 exactly like amt_v2_decide_batch, writes that position's chord-stream row into ws (the input of the next call,
+ * which therefore starts at the first projection: pass first = 1 only for the first call of a generation, whose input row is
+ * computed from state_dev) and advances state_dev[0].  state_dev: 2 + 2B int32 {position, root[B], attr[B], ticket = 0}.
+ * Inside the chain: a mixture layer's routing happens in its combine kernel, the last layer's norm3 and decoder.norm both in the
+ * prologue of the output head. */
+int32_t amt_v2_step_decide_batch(const void* const* tab, int32_t n_layers, int32_t H, int32_t E, int32_t dff, int32_t n_exp,
+                                 int32_t S, int32_t max_seq, int32_t B, const float* keys_dev, int32_t* state_dev,
+                                 float* logits_out, float* ws, int64_t* tokens, int64_t* roots, int64_t* attrs, int32_t T,
+                                 int32_t n_primer, int32_t beam, int32_t max_conseq_N, int32_t max_conseq_chord, float temperature,
+                                 const float* uniforms, int32_t chord_embed, int32_t first, void* stream);
 
 /* ---- regression head VideoRegression(regModel='bimamba+') (model/video_regression.py:104-245) ---- */
 /* Depthwise causal Conv1d(kernel K, padding K-1)[..., :L] + SiLU of MambaBlock.forward (mamba.py:172-175,268-272):

@@ -172,7 +172,11 @@ def test_attention_decode(B, H, hd, cap, pos, rpr):
 
 
 @pytest.mark.parametrize("B,N,K,ln,relu,resid", [(32, 512, 512, True, 0, True), (1, 1536, 512, False, 0, False), (7, 1024, 512, True, 1, False),
-                                                (32, 512, 1024, False, 0, True), (3, 384, 128, True, 0, False), (5, 128, 256, False, 1, True)])
+                                                (32, 512, 1024, False, 0, True), (3, 384, 128, True, 0, False), (5, 128, 256, False, 1, True),
+                                                # wide products (several column tiles per workgroup): the MoE gate|up stack of config 2,
+                                                # a tile count that is not a multiple of the tiles per workgroup, K = 1024
+                                                (32, 14336, 512, True, 0, False), (20, 4112, 512, False, 1, True), (32, 4096, 1024, True, 0, True),
+                                                (9, 6000, 1024, False, 0, False)])
 def test_decode_linear(B, N, K, ln, relu, resid):
     rs = np.random.RandomState(N + K + B)
     x, w, b = rnd(rs, B, K, scale=2.0), rnd(rs, N, K, scale=K ** -0.5), rnd(rs, N)

@@ -47,6 +47,7 @@ SIGNATURES = {
     "amt_generate_end": [_P, _P, _P],
     "amt_generate": [_P, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P],
     "amt_v2_decide_batch": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P],
+    "amt_v2_step_decide_batch": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _I, _I, _P],
     "amt_debug_set_skip": [_P, _I],
     "amt_decode_step_bytes": [_P, _I, _I, _I],
     "amt_linear_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -14,6 +14,8 @@
 //    fixed order through LDS (deterministic, no atomics);
 //  * the (normalised) input rows are staged once in LDS ([16][K+8] floats: conflict-free
 //    ds_read_b128 A-fragments).
+#include <stdlib.h>
+
 #include <mutex>
 
 #include "amt_common.h"
@@ -106,13 +108,22 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
         }
     }
     // ---- 2. prologue vectors ----
-    float4 g0[PRO == 1 ? KCH : 1], h0[PRO == 1 ? KCH : 1];
-    if (PRO == 1) {
+    constexpr bool LN1 = PRO == 1 || PRO == 4;      // PRO 4: two LayerNorms in a row (norm3 of the last layer, then decoder.norm)
+    float4 g0[LN1 ? KCH : 1], h0[LN1 ? KCH : 1], g1[PRO == 4 ? KCH : 1], h1[PRO == 4 ? KCH : 1];
+    if (LN1) {
 #pragma unroll
         for (int c = 0; c < KCH; ++c) {
             const int i = (c * 64 + lane) * 4, ic = FULL ? i : min(i, K - 4);
             g0[c] = ld4(p.ln_w + ic);
             h0[c] = ld4(p.ln_b + ic);
+        }
+    }
+    if (PRO == 4) {
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            const int i = (c * 64 + lane) * 4, ic = FULL ? i : min(i, K - 4);
+            g1[c] = ld4(p.ln2_w + ic);
+            h1[c] = ld4(p.ln2_b + ic);
         }
     }
     // folded FFN: the per-column vectors (same for all 16 rows) go through LDS, one float4 per thread (K/2 <= 1024)
@@ -184,26 +195,30 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
                 v[c].w = fmaxf((v[c].w - (rawh ? mean * g.w : mean)) * rstd * (rawh ? 1.f : g.w) + h.w, lo);
             }
         }
-    } else if (PRO == 1) {
+    } else if (LN1) {
         const float inv_k = 1.0f / (float)K;
-        float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < KCH; ++c) {
-            const int i = (c * 64 + lane) * 4;
-            if (FULL || i < K) s += sum4(v[c]);
-        }
-        const float mean = wave_sum(s) * inv_k;
-        float q = 0.f;
+        for (int pass = 0; pass < (PRO == 4 ? 2 : 1); ++pass) {
+            float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < KCH; ++c) {
-            const int i = (c * 64 + lane) * 4;
-            if (FULL || i < K) q += sq4(v[c], mean);
-        }
-        const float rstd = rsqrtf(wave_sum(q) * inv_k + p.eps);
+            for (int c = 0; c < KCH; ++c) {
+                const int i = (c * 64 + lane) * 4;
+                if (FULL || i < K) s += sum4(v[c]);
+            }
+            const float mean = wave_sum(s) * inv_k;
+            float q = 0.f;
 #pragma unroll
-        for (int c = 0; c < KCH; ++c) {
-            v[c].x = (v[c].x - mean) * rstd * g0[c].x + h0[c].x; v[c].y = (v[c].y - mean) * rstd * g0[c].y + h0[c].y;
-            v[c].z = (v[c].z - mean) * rstd * g0[c].z + h0[c].z; v[c].w = (v[c].w - mean) * rstd * g0[c].w + h0[c].w;
+            for (int c = 0; c < KCH; ++c) {
+                const int i = (c * 64 + lane) * 4;
+                if (FULL || i < K) q += sq4(v[c], mean);
+            }
+            const float rstd = rsqrtf(wave_sum(q) * inv_k + p.eps);
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) {
+                const float4 g = (PRO == 4 && pass == 1) ? g1[c] : g0[c], h = (PRO == 4 && pass == 1) ? h1[c] : h0[c];
+                v[c].x = (v[c].x - mean) * rstd * g.x + h.x; v[c].y = (v[c].y - mean) * rstd * g.y + h.y;
+                v[c].z = (v[c].z - mean) * rstd * g.z + h.z; v[c].w = (v[c].w - mean) * rstd * g.w + h.w;
+            }
         }
     }
     if (PRO == 3) {
@@ -235,7 +250,7 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
 
     // the normalised rows are the residual of the following block: workgroup (nt, m-block) publishes its
     // 16 rows x columns 16nt..16nt+15
-    if (PRO == 1 && p.xn && nt * 16 < K && tid < 256) {
+    if (LN1 && p.xn && nt * 16 < K && tid < 256) {
         const int rr = tid >> 4, c = tid & 15;
         if (m0 + rr < p.B) p.xn[(size_t)(m0 + rr) * K + nt * 16 + c] = xs[rr * LD + nt * 16 + c];
     }
@@ -333,10 +348,156 @@ int32_t launch_one(const DecodeGemmParams& p, size_t lds, hipStream_t stream) {
     return 0;
 }
 
+// Wide products (N >= 4096: the stacked gate|up projection of a mixture-of-experts layer, 7 x 2 x dff columns): with one 16-column
+// tile per workgroup such a launch is 1792 workgroups of two weight tiles per wave each, i.e. several rounds of the fixed
+// stage-rows / barrier / reduce latency over the chip (16.3 us for 29 MB at config 2).  Here a workgroup keeps its 16 staged rows
+// and walks NTW column tiles: all NTW x KCH weight tiles of a wave are in flight before the prologue, the rows are staged and
+// normalised once, and every thread takes part in the final reduction (thread group j reduces tile j).  Same arithmetic per output
+// as decode_gemm_kernel (same k order inside a wave, same fixed wave order in the reduction): results are bit-identical.
+// Plain single-source products only: PRO 0 / 1, packed weights, mode 0, no column split, no rotary epilogue.
+template <int KCH, int PRO, int NTW>
+__global__ __launch_bounds__(NW * 64) void decode_gemm_wide_kernel(DecodeGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int K = KCH * 256, LD = K + XPAD, kt_n = K / 16;
+    float* xs = smem;                               // [16][LD]
+    float* red = smem;                              // [NTW][16 waves][256], reuses xs after the MFMA phase
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // 1-D grid: the row blocks of one tile group are 8 linear ids apart, i.e. dispatched back to back onto the SAME XCD (round-robin
+    // placement), so the group's weight tiles cross HBM / the Infinity Cache once and the second row block finds them in that L2
+    const int mb = (p.B + MT - 1) / MT, n_tiles = (p.N + 15) >> 4;
+    const int grp = ((int)blockIdx.x / (8 * mb)) * 8 + ((int)blockIdx.x & 7);
+    if (grp * NTW >= n_tiles) return;               // the grid is padded to whole sets of 8 groups (uniform per workgroup)
+    const int nt0 = grp * NTW, m0 = (((int)blockIdx.x >> 3) % mb) * MT;
+    const int kt0 = wave * KCH;
+    const int r = m0 + wave, rc = min(r, p.B - 1);
+    const float* xr = p.x + (size_t)rc * p.ldx;
+    float4 v[KCH];
+#pragma unroll
+    for (int c = 0; c < KCH; ++c) v[c] = ld4(xr + (c * 64 + lane) * 4);
+    float4 g0[PRO == 1 ? KCH : 1], h0[PRO == 1 ? KCH : 1];
+    if (PRO == 1) {
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            g0[c] = ld4(p.ln_w + (c * 64 + lane) * 4);
+            h0[c] = ld4(p.ln_b + (c * 64 + lane) * 4);
+        }
+    }
+    float4 wt[NTW][KCH];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const float* wbase = p.Wp + (size_t)min(nt0 + j, n_tiles - 1) * kt_n * 256;      // surplus tiles repeat the last one
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) wt[j][i] = ld4(wbase + ((size_t)(kt0 + i) * 64 + lane) * 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (PRO == 1) {
+        const float inv_k = 1.0f / (float)K;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) s += sum4(v[c]);
+        const float mean = wave_sum(s) * inv_k;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) q += sq4(v[c], mean);
+        const float rstd = rsqrtf(wave_sum(q) * inv_k + p.eps);
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            v[c].x = (v[c].x - mean) * rstd * g0[c].x + h0[c].x; v[c].y = (v[c].y - mean) * rstd * g0[c].y + h0[c].y;
+            v[c].z = (v[c].z - mean) * rstd * g0[c].z + h0[c].z; v[c].w = (v[c].w - mean) * rstd * g0[c].w + h0[c].w;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < KCH; ++c) st4(xs + wave * LD + (c * 64 + lane) * 4, v[c]);
+    __syncthreads();
+
+    // thread (jg, e) owns output e of tiles nt0 + jg, nt0 + jg + 4, ...
+    constexpr int JN = (NTW + 3) / 4;
+    const int jg = tid >> 8, e = tid & 255;
+    const int el = e & 63, er = (e >> 6) & 3;
+    const int row = m0 + 4 * (el >> 4) + er;
+    float e_bias[JN], e_res[JN];
+#pragma unroll
+    for (int q = 0; q < JN; ++q) {
+        const int j = jg + 4 * q, n = (nt0 + j) * 16 + (el & 15);
+        const bool live = j < NTW && row < p.B && n < p.N;
+        e_bias[q] = *((live && p.bias) ? p.bias + n : p.zero);
+        e_res[q] = *((live && p.resid) ? p.resid + (size_t)row * p.ldr + n : p.zero);
+        if (PRO == 1 && p.xn && j < NTW && (nt0 + j) * 16 < K) {
+            const int rr = e >> 4, c = e & 15;
+            if (m0 + rr < p.B) p.xn[(size_t)(m0 + rr) * K + (nt0 + j) * 16 + c] = xs[rr * LD + (nt0 + j) * 16 + c];
+        }
+    }
+
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* xa = xs + (lane & 15) * LD + kt0 * 16 + 4 * (lane >> 4);
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+        const float4 a0 = ld4(xa + i * 16);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const float4 w = wt[j][i];
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w.x, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, w.y, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, w.z, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, w.w, acc[j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        float* rw = red + (j * NW + wave) * 256;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) rw[rr * 64 + lane] = acc[j][rr];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < JN; ++q) {
+        const int j = jg + 4 * q, n = (nt0 + j) * 16 + (el & 15);
+        if (j < NTW) {
+            float val = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) val += red[(j * NW + w) * 256 + e];
+            val += e_bias[q];
+            if (row < p.B && n < p.N) {
+                if (n < p.scale_cols) val *= p.scale;
+                val += e_res[q];
+                if (p.relu) val = fmaxf(val, 0.f);
+                p.y[(size_t)row * p.ldy + n] = val;
+            }
+        }
+    }
+}
+
+template <int KCH, int PRO, int NTW>
+int32_t launch_wide(const DecodeGemmParams& p, hipStream_t stream) {
+    static bool attr_set[64] = {false};
+    static std::mutex mu;
+    int dev = 0;
+    AMT_HIP(hipGetDevice(&dev));
+    AMT_CHECK_ARG(dev >= 0 && dev < 64, "decode_gemm: device ordinal %d out of range", dev);
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!attr_set[dev]) {
+            AMT_HIP(hipFuncSetAttribute((const void*)decode_gemm_wide_kernel<KCH, PRO, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set[dev] = true;
+        }
+    }
+    size_t lds = (size_t)MT * (KCH * 256 + XPAD) * sizeof(float);
+    const size_t lr = (size_t)NTW * NW * 256 * sizeof(float);
+    if (lds < lr) lds = lr;
+    const int groups8 = cdiv(cdiv(cdiv(p.N, 16), NTW), 8) * 8;
+    hipLaunchKernelGGL((decode_gemm_wide_kernel<KCH, PRO, NTW>), dim3(groups8 * cdiv(p.B, MT)), dim3(NW * 64), lds, stream, p);
+    AMT_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int KCH, bool FULL>
 int32_t launch_variant(const DecodeGemmParams& p, size_t lds, hipStream_t stream) {
     if (p.pro == 1) return launch_one<KCH, FULL, 2>(p, lds, stream);
     if (p.glu_gate) return launch_one<KCH, FULL, 3>(p, lds, stream);
+    if (p.ln_w && p.ln2_w) { if constexpr (KCH <= 4) return launch_one<KCH, FULL, 4>(p, lds, stream); }
     if (p.ln_w) { if constexpr (KCH <= 4) return launch_one<KCH, FULL, 1>(p, lds, stream); }
     return launch_one<KCH, FULL, 0>(p, lds, stream);
 }
@@ -388,6 +549,19 @@ int32_t amt_launch_decode_gemm(const DecodeGemmParams& p_in, hipStream_t stream)
     AMT_CHECK_ARG(!p.rope || (p.pos && p.rope_dim > 0 && p.rope_dim % 2 == 0 && p.rope_cols % 2 == 0 && p.n_split == 0), "decode_gemm: bad rotary epilogue");
     if (p.pro == 1) AMT_CHECK_ARG(p.x2 && p.fold_g && p.fold_c && p.ln_w && p.ln_b && !p.resid, "decode_gemm: incomplete folded-FFN prologue");
     else AMT_CHECK_ARG(!p.ln_w || (!p.x2 && p.K <= 1024), "decode_gemm: the LayerNorm prologue takes a single source of K <= 1024");
+    AMT_CHECK_ARG(!p.ln2_w || (p.ln_w && p.ln_b && p.ln2_b && p.pro == 0 && !p.glu_gate), "decode_gemm: the second LayerNorm follows a first one");
+    // wide plain products: several column tiles per workgroup (see decode_gemm_wide_kernel)
+    static int wide_ntw = -1;
+    if (wide_ntw < 0) { const char* e = getenv("AMT_WIDE_NTW"); wide_ntw = e ? atoi(e) : 4; }
+    if (wide_ntw > 0 && p.N >= 4096 && !p.x2 && p.n_split == 0 && !p.sel && p.n_groups <= 1 && p.mode == 0 && !p.rope && !p.glu_gate && p.pro == 0 &&
+        p.ldw == 0 && (p.K == 512 || p.K == 1024) && (!p.ln_w || p.ln_b) && !p.ln2_w) {
+        const bool ln = p.ln_w != nullptr;
+        if (p.K == 512) {
+            if (wide_ntw == 7) return ln ? launch_wide<2, 1, 7>(p, stream) : launch_wide<2, 0, 7>(p, stream);
+            return ln ? launch_wide<2, 1, 4>(p, stream) : launch_wide<2, 0, 4>(p, stream);
+        }
+        return ln ? launch_wide<4, 1, 4>(p, stream) : launch_wide<4, 0, 4>(p, stream);
+    }
     size_t lds = (size_t)MT * (p.K + XPAD) * sizeof(float);
     if (lds < (size_t)NW * 256 * sizeof(float)) lds = (size_t)NW * 256 * sizeof(float);
     if (p.pro == 1) lds += (size_t)2 * p.K * sizeof(float);

@@ -140,6 +140,7 @@ struct DecodeGemmParams {
     const float* zero;          // set by the launcher: zero words in global memory
     // diagnostic builds only (-DAMT_STAMPS, tools/ubench_chain.cpp): [workgroup][8] s_memrealtime stamps (100 MHz) of the
     // kernel's phases; null and unused in the library build
+    const float* ln2_w; const float* ln2_b;   // a second LayerNorm applied to the normalised rows (norm3 of the last layer, then decoder.norm)
     unsigned long long* stamps;
 };
 int32_t amt_launch_decode_gemm(const DecodeGemmParams& p, hipStream_t stream);
@@ -150,6 +151,14 @@ int32_t amt_decode_gemm_init();
 // dense_B > 0: Y holds every expert's output for every token ([expert][dense_B][d]), slot_pos is not read
 int32_t amt_launch_moe_combine(const float* y_rows, const int32_t* slot_pos, const int32_t* idx, const float* wts, const float* shared,
                                float shared_scale, const float* resid, float* out, int n_tok, int d, hipStream_t stream, int dense_B = 0);
+// decision + next chord-stream row + position advance of the lockstep V1/V2 step, one launch (sample.hip)
+int32_t amt_launch_v2_decide_fused(const float* logits, int ld_logits, int32_t* state_dev, int64_t* tokens, int64_t* roots, int64_t* attrs,
+                                   int B, int T, int n_primer, int beam, int max_conseq_N, int max_conseq_chord, float temperature,
+                                   const float* uniforms, int chord_embed, const float* keys, const float* PR, const float* PA,
+                                   const float* wkey, const float* bias, const float* pe, float* x_next, int d, hipStream_t stream);
+// routing (top-2 of x . gate_w^T + gate_b, softmax over the pair) and the combine in one launch; y_all is [expert][n_tok][d]
+int32_t amt_launch_moe_route_combine(const float* x, const float* gate_w, const float* gate_b, int n_exp, const float* y_all, const float* shared,
+                                     float shared_scale, const float* resid, float* out, int n_tok, int d, hipStream_t stream);
 
 // ---------------- load-time LayerNorm folding (fold.hip) ----------------
 int32_t amt_launch_scale_cols(const float* W, const float* gamma, float* out, int N, int K, hipStream_t stream);   // out = W o gamma

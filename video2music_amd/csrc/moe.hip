@@ -16,30 +16,39 @@ namespace {
 
 constexpr int TILE = 128;
 
-__global__ __launch_bounds__(256) void moe_route_kernel(const float* __restrict__ x, const float* __restrict__ gw,
-                                                        const float* __restrict__ gb, int n_tok, int d, int n_exp,
-                                                        int* __restrict__ idx, float* __restrict__ wts) {
-    const int lane = threadIdx.x & 63;
-    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tok >= n_tok) return;
+// top-2 routing of one token by one wave: gate logits, the two largest (largest first like torch.topk), softmax over the pair
+// (moe.py:190,288).  Every lane returns the same values.
+__device__ __forceinline__ void route_token(const float* __restrict__ xrow, const float* __restrict__ gw, const float* __restrict__ gb,
+                                            int d, int n_exp, int lane, int& i0, int& i1, float& w0, float& w1) {
     float best0 = -INFINITY, best1 = -INFINITY;
-    int i0 = 0, i1 = 0;
+    i0 = 0; i1 = 0;
     for (int e = 0; e < n_exp; ++e) {
         float s = 0.f;
         for (int c = lane * 4; c < d; c += 256) {
-            const float4 a = ld4(x + (size_t)tok * d + c), w = ld4(gw + (size_t)e * d + c);
+            const float4 a = ld4(xrow + c), w = ld4(gw + (size_t)e * d + c);
             s += a.x * w.x + a.y * w.y + a.z * w.z + a.w * w.w;
         }
         s = wave_sum(s) + (gb ? gb[e] : 0.f);
         if (s > best0) { best1 = best0; i1 = i0; best0 = s; i0 = e; }
         else if (s > best1) { best1 = s; i1 = e; }
     }
+    const float e1 = __expf(best1 - best0);
+    w0 = 1.0f / (1.0f + e1);
+    w1 = e1 * w0;
+}
+
+__global__ __launch_bounds__(256) void moe_route_kernel(const float* __restrict__ x, const float* __restrict__ gw,
+                                                        const float* __restrict__ gb, int n_tok, int d, int n_exp,
+                                                        int* __restrict__ idx, float* __restrict__ wts) {
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= n_tok) return;
+    int i0, i1;
+    float w0, w1;
+    route_token(x + (size_t)tok * d, gw, gb, d, n_exp, lane, i0, i1, w0, w1);
     if (lane == 0) {
-        // softmax over the two selected logits (moe.py:190,288), largest first like torch.topk
-        const float e1 = __expf(best1 - best0);
-        const float inv = 1.0f / (1.0f + e1);
         idx[tok * 2] = i0; idx[tok * 2 + 1] = i1;
-        wts[tok * 2] = inv; wts[tok * 2 + 1] = e1 * inv;
+        wts[tok * 2] = w0; wts[tok * 2 + 1] = w1;
     }
 }
 
@@ -117,6 +126,46 @@ __global__ void moe_combine_kernel(const float* __restrict__ Y, const int* __res
             o.x += shared_scale * s.x; o.y += shared_scale * s.y; o.z += shared_scale * s.z; o.w += shared_scale * s.w;
         }
         if (resid) {                           // the layer's residual: out = mixture(x) + x (the sum the following norm takes)
+            const float4 r = ld4(resid + (size_t)tok * d + c);
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        st4(out + (size_t)tok * d + c, o);
+    }
+}
+
+// Routing and combine of the lockstep decode step in one launch (every expert was evaluated on every row: Y is
+// [expert][n_tok][d]): each block routes its own token (wave 0, same arithmetic as moe_route_kernel), then mixes the two rows in
+// expert-index order, adds the shared expert and the layer's residual.
+__global__ __launch_bounds__(128) void moe_route_combine_kernel(const float* __restrict__ x, const float* __restrict__ gw, const float* __restrict__ gb,
+                                                                int n_exp, const float* __restrict__ Y, const float* __restrict__ shared,
+                                                                float shared_scale, const float* __restrict__ resid, float* __restrict__ out,
+                                                                int n_tok, int d) {
+    __shared__ int s_i[2];
+    __shared__ float s_w[2];
+    const int tok = blockIdx.x;
+    if (threadIdx.x < 64) {
+        int i0, i1;
+        float w0, w1;
+        route_token(x + (size_t)tok * d, gw, gb, d, n_exp, threadIdx.x, i0, i1, w0, w1);
+        if (threadIdx.x == 0) {
+            const bool sw = i0 > i1;                         // accumulate in expert-index order (moe.py:191-199)
+            s_i[0] = sw ? i1 : i0; s_i[1] = sw ? i0 : i1;
+            s_w[0] = sw ? w1 : w0; s_w[1] = sw ? w0 : w1;
+        }
+    }
+    __syncthreads();
+    const float wa = s_w[0], wb = s_w[1];
+    const float* ya = Y + ((size_t)s_i[0] * n_tok + tok) * d;
+    const float* yb = Y + ((size_t)s_i[1] * n_tok + tok) * d;
+    for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
+        const float4 p = ld4(ya + c), q = ld4(yb + c);
+        float4 o;
+        o.x = wa * p.x + wb * q.x; o.y = wa * p.y + wb * q.y; o.z = wa * p.z + wb * q.z; o.w = wa * p.w + wb * q.w;
+        if (shared) {
+            const float4 sh = ld4(shared + (size_t)tok * d + c);
+            o.x += shared_scale * sh.x; o.y += shared_scale * sh.y; o.z += shared_scale * sh.z; o.w += shared_scale * sh.w;
+        }
+        if (resid) {
             const float4 r = ld4(resid + (size_t)tok * d + c);
             o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
@@ -239,6 +288,15 @@ extern "C" int32_t amt_glu_expert_fwd(const float* x, const float* w1, const flo
 int32_t amt_launch_moe_combine(const float* y_rows, const int32_t* slot_pos, const int32_t* idx, const float* wts, const float* shared,
                                float shared_scale, const float* resid, float* out, int n_tok, int d, hipStream_t stream, int dense_B) {
     hipLaunchKernelGGL(moe_combine_kernel, dim3(n_tok), dim3(128), 0, stream, y_rows, slot_pos, idx, wts, shared, shared_scale, out, d, resid, dense_B);
+    AMT_LAUNCH_CHECK();
+    return 0;
+}
+
+int32_t amt_launch_moe_route_combine(const float* x, const float* gate_w, const float* gate_b, int n_exp, const float* y_all, const float* shared,
+                                     float shared_scale, const float* resid, float* out, int n_tok, int d, hipStream_t stream) {
+    AMT_CHECK_ARG(n_tok > 0 && n_exp >= 2 && n_exp <= 64 && d % 4 == 0, "moe_route_combine: bad shape");
+    hipLaunchKernelGGL(moe_route_combine_kernel, dim3(n_tok), dim3(128), 0, stream, x, gate_w, gate_b, n_exp, y_all, shared, shared_scale, resid, out,
+                       n_tok, d);
     AMT_LAUNCH_CHECK();
     return 0;
 }

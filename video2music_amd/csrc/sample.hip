@@ -499,7 +499,105 @@ __global__ __launch_bounds__(64) void v2_decide_kernel(const float* __restrict__
     }
 }
 
+// The same decision as the tail of ONE launch chain (amt_v2_step_decide_batch): state[0] still holds the position whose logits were
+// just computed, the kernel decides position cur = state[0] + 1, writes the chord-stream row of that position (the input of the
+// next step: what embed_rows_kernel computes at the head of amt_v2_step_batch) and the last block to finish advances state[0]
+// (ticket in state[1 + 2B]; every block has read state[0] before it takes its ticket).
+__global__ __launch_bounds__(64) void v2_decide_fused_kernel(const float* __restrict__ logits, int ld_logits, int32_t* __restrict__ state,
+                                                            int64_t* __restrict__ tokens, int64_t* __restrict__ roots, int64_t* __restrict__ attrs,
+                                                            int B, int T, int n_primer, int beam, int max_conseq_N, int max_conseq_chord,
+                                                            float inv_temperature, const float* __restrict__ uniforms, int chord_embed,
+                                                            const float* __restrict__ keys, const float* __restrict__ PR, const float* __restrict__ PA,
+                                                            const float* __restrict__ wkey, const float* __restrict__ bias,
+                                                            const float* __restrict__ pe, float* __restrict__ x_next, int d) {
+    __shared__ int s_ra[2];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int cur = state[0] + 1;
+    if (cur < T) {
+        if (cur >= n_primer) {
+            const float* lg = logits + (size_t)b * ld_logits;
+            float z[3];
+            float m = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int n = lane + 64 * k;
+                z[k] = n < V ? lg[n] * inv_temperature : -INFINITY;
+                m = fmaxf(m, z[k]);
+            }
+            m = wave_max(m);
+            float pr[3];
+            float ps = 0.f;
+            const int64_t prev = tokens[(size_t)b * T + cur - 1];
+            bool rep = beam == 0 && cur >= max_conseq_chord;
+            for (int k = 1; rep && k < max_conseq_chord; ++k) rep = tokens[(size_t)b * T + cur - 1 - k] == prev;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int n = lane + 64 * k;
+                float e = n < VP ? __expf(z[k] - m) : 0.f;
+                if (beam == 0 && ((max_conseq_N == 0 && n == 0) || (rep && n == (int)prev))) e = 0.f;
+                pr[k] = e;
+                ps += e;
+            }
+            ps = wave_sum(ps);
+            SampleParams sp{};
+            sp.beam = beam; sp.uniforms = uniforms; sp.B = B;
+            const int tok = pick_token(sp, pr, ps, lane, b, cur - 1);
+            if (lane == 0) {
+                tokens[(size_t)b * T + cur] = tok;
+                int root = ROOT_PAD, attr = ATTR_PAD;
+                if (chord_embed) { root = tok; attr = 0; }
+                else if (beam == 0) { root = tok == 0 ? 0 : (tok - 1) / 13 + 1; attr = tok == 0 ? 1 : (tok - 1) % 13 + 1; }
+                roots[(size_t)b * T + cur] = root;
+                attrs[(size_t)b * T + cur] = attr;
+            }
+        }
+        __syncthreads();
+        if (lane == 0) {
+            s_ra[0] = (int)roots[(size_t)b * T + cur];
+            s_ra[1] = (int)attrs[(size_t)b * T + cur];
+            state[1 + b] = s_ra[0];
+            state[1 + B + b] = s_ra[1];
+        }
+        __syncthreads();
+        // x_next[b] = chord-stream row of position cur (the summation order of embed_rows_kernel)
+        const int root = s_ra[0], attr = s_ra[1];
+        const float kv = keys[b];
+        const float* pp_row = pe ? pe + (size_t)cur * d : nullptr;
+        for (int c = lane * 4; c < d; c += 256) {
+            const float4 pr4 = ld4(PR + (size_t)root * d + c), pa = ld4(PA + (size_t)attr * d + c);
+            const float4 wk = ld4(wkey + c), bb = ld4(bias + c);
+            const float4 pp = pp_row ? ld4(pp_row + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 o;
+            o.x = ((pr4.x + pa.x) + kv * wk.x + bb.x) + pp.x; o.y = ((pr4.y + pa.y) + kv * wk.y + bb.y) + pp.y;
+            o.z = ((pr4.z + pa.z) + kv * wk.z + bb.z) + pp.z; o.w = ((pr4.w + pa.w) + kv * wk.w + bb.w) + pp.w;
+            st4(x_next + (size_t)b * d + c, o);
+        }
+    }
+    // advance: the last block to arrive publishes the new position and re-arms the ticket
+    if (lane == 0) {
+        __threadfence();
+        const int ticket = atomicAdd(&state[1 + 2 * B], 1);
+        if (ticket == B - 1) {
+            state[1 + 2 * B] = 0;
+            state[0] = cur;
+        }
+    }
+}
+
 }  // namespace
+
+int32_t amt_launch_v2_decide_fused(const float* logits, int ld_logits, int32_t* state_dev, int64_t* tokens, int64_t* roots, int64_t* attrs,
+                                   int B, int T, int n_primer, int beam, int max_conseq_N, int max_conseq_chord, float temperature,
+                                   const float* uniforms, int chord_embed, const float* keys, const float* PR, const float* PA,
+                                   const float* wkey, const float* bias, const float* pe, float* x_next, int d, hipStream_t stream) {
+    AMT_CHECK_ARG(logits && state_dev && tokens && roots && attrs && keys && PR && PA && wkey && bias && x_next, "v2_decide_fused: null pointer");
+    AMT_CHECK_ARG(B > 0 && T > 1 && n_primer >= 1 && n_primer <= T && ld_logits >= 159 && d % 4 == 0, "v2_decide_fused: bad shape");
+    AMT_CHECK_ARG((beam == 0 || beam == 1) && max_conseq_chord >= 1 && temperature > 0.f, "v2_decide_fused: bad decision parameters");
+    hipLaunchKernelGGL(v2_decide_fused_kernel, dim3(B), dim3(64), 0, stream, logits, ld_logits, state_dev, tokens, roots, attrs, B, T, n_primer, beam,
+                       max_conseq_N, max_conseq_chord, 1.0f / temperature, uniforms, chord_embed, keys, PR, PA, wkey, bias, pe, x_next, d);
+    AMT_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int32_t amt_v2_decide_batch(const float* logits, int32_t ld_logits, int32_t* state_dev, int64_t* tokens, int64_t* roots,
                                        int64_t* attrs, int32_t B, int32_t T, int32_t n_primer, int32_t beam, int32_t max_conseq_N,

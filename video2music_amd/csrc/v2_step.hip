@@ -316,6 +316,7 @@ struct RowGemm {
     const float* x = nullptr; int ldx = 0; const float* wp = nullptr; const float* b = nullptr; const float* resid = nullptr;
     float* y = nullptr; int N = 0, K = 0;
     const float* ln_w = nullptr; const float* ln_b = nullptr; float* xn = nullptr;
+    const float* ln2_w = nullptr; const float* ln2_b = nullptr;
     const float* rope = nullptr; int rope_cols = 0, rope_dim = 0; const int* pos = nullptr; float scale = 1.f; int scale_cols = 0;
     bool qkv = false; float* kc = nullptr; float* vc = nullptr; int H = 0, hd = 0, cap = 0;
     const float* gate = nullptr; bool gate_only = false;
@@ -327,7 +328,7 @@ int32_t row_gemm(const RowGemm& r, int B, hipStream_t s) {
     g.B = B; g.eps = 1e-5f; g.scale = r.scale; g.scale_cols = r.scale_cols;
     g.x = r.x ? r.x : r.gate; g.ldx = r.ldx ? r.ldx : r.K; g.Wp = r.wp; g.bias = r.b; g.N = r.N; g.K = r.K;
     g.resid = r.resid; g.ldr = r.N; g.y = r.y; g.ldy = r.qkv ? r.N / 3 : r.N;
-    g.ln_w = r.ln_w; g.ln_b = r.ln_b; g.xn = r.xn;
+    g.ln_w = r.ln_w; g.ln_b = r.ln_b; g.xn = r.xn; g.ln2_w = r.ln2_w; g.ln2_b = r.ln2_b;
     g.rope = r.rope; g.rope_cols = r.rope_cols; g.rope_dim = r.rope_dim; g.pos = r.pos;
     if (r.qkv) { g.mode = 1; g.kcache = r.kc; g.vcache = r.vc; g.H = r.H; g.hd = r.hd; g.cap = r.cap; g.d = r.N / 3; }
     g.glu_gate = r.gate; g.glu_only = r.gate && !r.x;
@@ -337,9 +338,11 @@ int32_t row_gemm(const RowGemm& r, int B, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int32_t amt_v2_step_batch(const void* const* tab, int32_t n_layers, int32_t H, int32_t E, int32_t dff, int32_t n_exp,
-                                     int32_t S, int32_t max_seq, int32_t B, const float* keys_dev, int32_t* state_dev,
-                                     float* logits_out, float* ws, void* stream) {
+// embed: compute the chord-stream rows of this position at the head of the chain (false: the previous call's fused decision left them
+// in ws); advance: increment the position at the tail (false: the fused decision does it)
+static int32_t v2_step_batch_impl(const void* const* tab, int32_t n_layers, int32_t H, int32_t E, int32_t dff, int32_t n_exp,
+                                  int32_t S, int32_t max_seq, int32_t B, const float* keys_dev, int32_t* state_dev,
+                                  float* logits_out, float* ws, void* stream, bool embed, bool advance) {
     AMT_CHECK_ARG(tab && logits_out && ws && keys_dev && state_dev, "amt_v2_step_batch: null pointer");
     AMT_CHECK_ARG(n_layers > 0 && H > 0 && E % H == 0 && E % 64 == 0 && dff % 64 == 0 && E <= 1536 && dff <= 1536 && S > 0 && max_seq > 0,
                   "amt_v2_step_batch: bad shape (E and dff must be multiples of 64, at most 1536)");
@@ -354,12 +357,12 @@ extern "C" int32_t amt_v2_step_batch(const void* const* tab, int32_t n_layers, i
     float* xa = ysh + BE; float* xb = xa + BE; float* xc = xb + BE;      // LayerNorm outputs written by the fused prologues
     float* Yall = xc + BE;                                // every expert's output [n_exp][B][E]
     float* ffs = Yall + (size_t)(n_exp + 1) * BE;         // 3 * B * (max(n_exp, 1) + 1) * dff expert scratch (gate | up of every expert + shared)
-    float* moe_w = ffs + (size_t)3 * B * ((n_exp > 0 ? n_exp : 1) + 1) * dff;   // routing weights [B][2], indices [B][2]
-    int32_t* moe_idx = (int32_t*)(moe_w + 2 * B);
     const int* pos = state_dev;
     int32_t rc;
-    hipLaunchKernelGGL(embed_rows_kernel, dim3(B), dim3(128), 0, s, state_dev, B, keys_dev, G(G_PR), G(G_PA), G(G_WKEY), G(G_CBIAS), x, E, G(G_PE));
-    AMT_LAUNCH_CHECK();
+    if (embed) {
+        hipLaunchKernelGGL(embed_rows_kernel, dim3(B), dim3(128), 0, s, state_dev, B, keys_dev, G(G_PR), G(G_PA), G(G_WKEY), G(G_CBIAS), x, E, G(G_PE));
+        AMT_LAUNCH_CHECK();
+    }
     const float* rope = G(G_ROPE);
     // A LayerNorm that feeds a projection runs in that projection's prologue (E <= 1024; RMSNorm models keep their own launch).
     // `cur` holds either finished rows (pend_w == null) or the pre-norm sum that the pending LayerNorm (pend_w, pend_b) completes.
@@ -424,28 +427,55 @@ extern "C" int32_t amt_v2_step_batch(const void* const* tab, int32_t n_layers, i
             rd.y = u; rd.N = E; rd.K = dff;
             if ((rc = row_gemm(rd, B, s))) return rc;             // u = expert(x) + x : the pre-norm sum of norm3
         } else {
-            if ((rc = amt_moe_route_fwd(ffin, P(L_GATEW), P(L_GATEB), moe_idx, moe_w, B, E, n_exp, s))) return rc;
             // the down projections of all experts and the shared one in ONE grouped launch (blockIdx.z = expert)
             RowGemm rd; rd.x = has_up ? GU + Nall : nullptr; rd.gate = GU; rd.ldx = Ngu; rd.wp = P(L_W2S); rd.b = P(L_B2S); rd.y = Yall; rd.N = E; rd.K = dff;
             rd.groups = ng; rd.x_goff = (size_t)dff; rd.y_goff = BE; rd.w_gstride = (size_t)E * dff; rd.b_gstride = E;
             if ((rc = row_gemm(rd, B, s))) return rc;
             const float* shared = L[L_SWG] ? Yall + (size_t)n_exp * BE : nullptr;
-            if ((rc = amt_launch_moe_combine(Yall, nullptr, moe_idx, moe_w, shared, 0.5f, ffin, u, B, E, s, B))) return rc;     // + residual
+            // top-2 routing of every row and the weighted sum of its two experts (+ shared / 2 + residual) in one launch
+            if ((rc = amt_launch_moe_route_combine(ffin, P(L_GATEW), P(L_GATEB), n_exp, Yall, shared, 0.5f, ffin, u, B, E, s))) return rc;
         }
         cur = u; pend_w = P(L_N3W); pend_b = P(L_N3B);
         // (the next layer's QKV launch consumes `u` before that layer's out-projection writes it again)
         if (l + 1 < n_layers && !(fuse_ln && pend_b)) { if ((rc = settle(x))) return rc; }
     }
-    if ((rc = settle(x))) return rc;                                     // norm3 of the last layer
-    if (fuse_ln && G(G_FNB)) {                                            // decoder.norm in the prologue of the output head
+    if (fuse_ln && pend_w && pend_b && G(G_FNB)) {                        // norm3 of the last layer AND decoder.norm in the head's prologue
+        RowGemm r; r.x = cur; r.wp = G(G_WOUT); r.b = G(G_BOUT); r.y = logits_out; r.N = 159; r.K = E; r.ln_w = pend_w; r.ln_b = pend_b;
+        r.ln2_w = G(G_FNW); r.ln2_b = G(G_FNB);
+        if ((rc = row_gemm(r, B, s))) return rc;
+        pend_w = pend_b = nullptr;
+    } else if ((rc = settle(x))) {                                        // norm3 of the last layer
+        return rc;
+    } else if (fuse_ln && G(G_FNB)) {                                     // decoder.norm in the prologue of the output head
         RowGemm r; r.x = cur; r.wp = G(G_WOUT); r.b = G(G_BOUT); r.y = logits_out; r.N = 159; r.K = E; r.ln_w = G(G_FNW); r.ln_b = G(G_FNB);
         if ((rc = row_gemm(r, B, s))) return rc;
     } else {
         if ((rc = norm_rows(cur, nullptr, G(G_FNW), G(G_FNB), y, B, E, s))) return rc;
         if ((rc = lin_rows(y, G(G_WOUT), G(G_BOUT), nullptr, logits_out, B, 159, E, s))) return rc;
     }
-    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, s, state_dev);
-    AMT_LAUNCH_CHECK();
+    if (advance) {
+        hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, s, state_dev);
+        AMT_LAUNCH_CHECK();
+    }
     return 0;
+}
+
+extern "C" int32_t amt_v2_step_batch(const void* const* tab, int32_t n_layers, int32_t H, int32_t E, int32_t dff, int32_t n_exp,
+                                     int32_t S, int32_t max_seq, int32_t B, const float* keys_dev, int32_t* state_dev,
+                                     float* logits_out, float* ws, void* stream) {
+    return v2_step_batch_impl(tab, n_layers, H, E, dff, n_exp, S, max_seq, B, keys_dev, state_dev, logits_out, ws, stream, true, true);
+}
+
+extern "C" int32_t amt_v2_step_decide_batch(const void* const* tab, int32_t n_layers, int32_t H, int32_t E, int32_t dff, int32_t n_exp,
+                                            int32_t S, int32_t max_seq, int32_t B, const float* keys_dev, int32_t* state_dev,
+                                            float* logits_out, float* ws, int64_t* tokens, int64_t* roots, int64_t* attrs, int32_t T,
+                                            int32_t n_primer, int32_t beam, int32_t max_conseq_N, int32_t max_conseq_chord, float temperature,
+                                            const float* uniforms, int32_t chord_embed, int32_t first, void* stream) {
+    int32_t rc = v2_step_batch_impl(tab, n_layers, H, E, dff, n_exp, S, max_seq, B, keys_dev, state_dev, logits_out, ws, stream, first != 0, false);
+    if (rc) return rc;
+    auto G = [&](int i) { return (const float*)tab[i]; };
+    return amt_launch_v2_decide_fused(logits_out, 159, state_dev, tokens, roots, attrs, B, T, n_primer, beam, max_conseq_N, max_conseq_chord,
+                                      temperature, uniforms, chord_embed, keys_dev, G(G_PR), G(G_PA), G(G_WKEY), G(G_CBIAS), G(G_PE), ws, E,
+                                      (hipStream_t)stream);
 }
 

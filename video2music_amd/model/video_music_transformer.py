@@ -19,6 +19,7 @@ Differences a caller can observe, all additive:
     because its logits at position i do not depend on the current length.
 """
 import ctypes as C
+import os
 import math
 import threading
 
@@ -1129,8 +1130,8 @@ class VideoMusicTransformer_V2(nn.Module):
 
     def _lockstep_device(self, st, keys, gen, gen_root, gen_attr, nb, T, P, beam, max_conseq_N, max_conseq_chord, temperature,
                          sampler, use_graph, uniforms):
-        """Lockstep generate with the decision on the device: (amt_v2_step_batch, amt_v2_decide_batch) for position 0 issued
-        eagerly, then that pair captured once and replayed for positions 1 .. T-2; one synchronisation at the end."""
+        """Lockstep generate with the decision on the device: amt_v2_step_decide_batch for position 0 issued eagerly, then that
+        chain captured once and replayed for positions 1 .. T-2; one synchronisation at the end."""
         dev = keys.device
         if sampler not in ("categorical", "argmax"):
             raise ValueError(f"unknown sampler {sampler!r}")
@@ -1139,27 +1140,41 @@ class VideoMusicTransformer_V2(nn.Module):
         if beam == 0 and sampler == "categorical":
             unif = (torch.rand(T, nb, device=dev) if uniforms is None else torch.as_tensor(uniforms, dtype=torch.float32).to(dev)).contiguous()
             assert unif.shape == (T, nb), "uniforms must be (target_seq_length, B)"
-        state = torch.zeros(1 + 2 * nb, dtype=torch.int32, device=dev)
-        state[1:] = torch.cat((gen_root[:, 0], gen_attr[:, 0])).to(torch.int32)
+        state = torch.zeros(2 + 2 * nb, dtype=torch.int32, device=dev)          # {position, root[B], attr[B], ticket}
+        state[1:1 + 2 * nb] = torch.cat((gen_root[:, 0], gen_attr[:, 0])).to(torch.int32)
 
-        def pair():
-            self._step_batch(st, keys, state)
-            _lib.call("amt_v2_decide_batch", _lib.ptr(st["logits"]), CHORD_SIZE, _lib.ptr(state), _lib.ptr(tokens), _lib.ptr(roots),
-                      _lib.ptr(attrs), nb, T, P, int(beam), int(max_conseq_N), int(max_conseq_chord), float(temperature),
-                      _lib.ptr(unif), int(bool(self.chord_embed)), _lib.stream_ptr())
+        def step(first):
+            # one launch chain: the decoder step, then the decision, the next position's chord-stream row and the position
+            # advance in one kernel (amt_v2_step_decide_batch; `first`: the chain starts with the embedding of position 0)
+            _lib.call("amt_v2_step_decide_batch", st["tab"], len(self.transformer.decoder.layers), self.nhead, self.d_model, st["dff"],
+                      self.n_experts, st["S"], self._max_dec, st["B"], _lib.ptr(keys), _lib.ptr(state), _lib.ptr(st["logits"]),
+                      _lib.ptr(st["ws"]), _lib.ptr(tokens), _lib.ptr(roots), _lib.ptr(attrs), T, P, int(beam), int(max_conseq_N),
+                      int(max_conseq_chord), float(temperature), _lib.ptr(unif), int(bool(self.chord_embed)), int(first), _lib.stream_ptr())
 
-        pair()                                                          # position 0 (the warm-up a capture needs)
+        step(True)                                                      # position 0 (the warm-up a capture needs)
         if T > 2:
             if use_graph:
+                # the chain is captured twice: STEPS_PER_GRAPH steps in one graph (one host launch per 8 positions) and a single
+                # step for the remainder (a step past T - 2 would write a cache row that does not exist)
+                k = max(1, min(int(os.environ.get("AMT_V2_STEPS_PER_GRAPH", "8")), T - 2))
                 torch.cuda.current_stream().synchronize()
-                graph = torch.cuda.CUDAGraph()
-                with _CAPTURE_LOCK, torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    pair()
-                for _ in range(T - 2):
-                    graph.replay()
+                many, one = torch.cuda.CUDAGraph(), None
+                with _CAPTURE_LOCK, torch.cuda.graph(many, capture_error_mode="thread_local"):
+                    for _ in range(k):
+                        step(False)
+                # (capturing executes nothing: the positions start after it)
+                for _ in range((T - 2) // k):
+                    many.replay()
+                rest = (T - 2) % k
+                if rest:
+                    one = torch.cuda.CUDAGraph()
+                    with _CAPTURE_LOCK, torch.cuda.graph(one, capture_error_mode="thread_local"):
+                        step(False)
+                    for _ in range(rest):
+                        one.replay()
             else:
                 for _ in range(T - 2):
-                    pair()
+                    step(False)
         return tokens
 
     def _lockstep_loop(self, next_logits, gen, gen_root, gen_attr, ra_table, nb, T, P, beam, max_conseq_N, max_conseq_chord,
