@@ -263,13 +263,15 @@ int32_t amt_moe_combine_fwd(const float* y_rows, const int32_t* slot_pos, const 
  * amt_pack_weight_fwd (out: ceil(N/16)*16*K floats; the experts of a MoE layer are packed one after the other).
  * tab: device pointers, 11 global (PR, PA, wkey, Linear_chord.bias, rope cache (max_seq, E/2, 2) or null = no rotation,
  * decoder.norm w, b, packed Wout, Wout b, an int32 pair {0, 1}, learned positional table (max_seq, E) added to the
- * embedding of position t or null: version '2.0' has the table and no rotation, :375-380,497-503) then 36 per layer (packed self in_proj, its bias, packed out_proj, b,
+ * embedding of position t or null: version '2.0' has the table and no rotation, :375-380,497-503) then 40 per layer (packed self in_proj, its bias, packed out_proj, b,
  * norm1 w, b, packed cross in_proj rows 0:E, its bias, packed out_proj, b, norm2 w, b, norm3 w, b, self K cache, V cache
  * (head-major: H, max_seq, hd), cross K (roped), V (head-major: H, S, hd), router w (null = plain GLU layer), router b, packed linear1, b, packed gate, b,
  * packed linear2, b (per expert, stacked, for a MoE layer), shared expert's six tensors (packed weights) or null; then, for the
  * lockstep step, the stacked forms: packed [gate of every expert (+ the shared one) | linear1 of every expert (+ shared)] as one matrix
  * and its bias, packed linear2 of every expert (+ shared) one after the other and their biases (both null for a plain GLU layer,
- * whose linear2 is the per-layer entry above)).
+ * whose linear2 is the per-layer entry above); last, for the lockstep step with norm1 folded through the cross-attention's query
+ * projection (all four null: separate launches): packed [(Wq o gamma1) Wo | Wq o gamma1] (E x 2E), its bias (Wq o gamma1) bo,
+ * g = rowsum(Wq o gamma1), c = Wq beta1 + bq  (Wo, bo: self-attention out-projection; Wq, bq: cross in_proj rows 0:E)).
  * A null norm bias selects RMSNorm (eps 1e-6) for that norm; a null linear1 selects Linear -> SiLU -> Linear experts
  * (h = silu(gate-slot projection)): the V1 family (video_music_transformer.py:22-314).
  * ws: amt_v2_step_ws_floats(E, dff, n_exp) floats.  E, dff multiples of 64, at most 1536.

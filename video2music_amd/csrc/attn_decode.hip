@@ -106,7 +106,8 @@ __device__ __forceinline__ void stream_keys(Batch<HD>& cur, Batch<HD>& nxt, cons
 
 constexpr int UCH = 4;           // folded prologue: the pre-LN row has at most UCH*256 floats
 
-// FOLD: 0 plain query, 1 folded-LayerNorm prologue, 2 the same plus the new key/value of this position
+// FOLD: 0 plain query, 1 folded-LayerNorm prologue, 2 the same plus the new key/value of this position, 3 = 1 plus the rotary
+// embedding of the query (the lockstep V1/V2 step: q = rope(LayerNorm(u) . Wq^T + b) * scale)
 #ifdef AMT_STAMPS
 #define ASTAMP(i) do { __builtin_amdgcn_sched_barrier(0); st_[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnDecodeParams p
     // Vector loads return in issue order.  The long prologue of FOLD 2 (11 loads and their address math) goes
     // behind the first K/V batch so that the stream starts at once; the short one of FOLD 1 goes in front of it
     // so that the statistics are computed while the batch is in flight (measured both ways).
-    if (FOLD != 1) load_kv<HD, NT>(b0, kb, vb, j0, sub, c4, p.cap);
+    constexpr bool F1 = FOLD == 1 || FOLD == 3;
+    if (!F1) load_kv<HD, NT>(b0, kb, vb, j0, sub, c4, p.cap);
     if (!FOLD) {
         q4 = ld4(p.q + ((size_t)b * p.H + h) * HD + c * 4);
     } else {
@@ -166,7 +168,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnDecodeParams p
             rk = ld4(raw + d); gk = ld4(p.fold_g + d + col); ck = ld4(p.fold_c + d + col);
             rv = ld4(raw + 2 * d); gv = ld4(p.fold_g + 2 * d + col); cv = ld4(p.fold_c + 2 * d + col);
         }
-        if (FOLD == 1) load_kv<HD, NT>(b0, kb, vb, j0, sub, c4, p.cap);
+        float4 rcs = make_float4(1.f, 0.f, 1.f, 0.f);
+        if (FOLD == 3) rcs = ld4(p.rope + (size_t)(*p.rope_pos) * p.rope_dim + (col % p.rope_dim));     // (cos, sin) of the lane's two pairs
+        if (F1) load_kv<HD, NT>(b0, kb, vb, j0, sub, c4, p.cap);
         // the first batch's Er rows need only the position: issued behind the prologue's loads, they land while the
         // statistics are reduced instead of costing one more L2 round trip after the query exists
         if (RPR && FOLD == 2) load_er<HD>(b0, eb, j0, sub, c4, n_keys);
@@ -184,8 +188,16 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnDecodeParams p
             }
         }
         const float rstd = rsqrtf(wave_sum(qq) * inv_d + p.eps);
-        q4.x = ((rq.x - mean * gq.x) * rstd + cq.x) * p.q_scale; q4.y = ((rq.y - mean * gq.y) * rstd + cq.y) * p.q_scale;
-        q4.z = ((rq.z - mean * gq.z) * rstd + cq.z) * p.q_scale; q4.w = ((rq.w - mean * gq.w) * rstd + cq.w) * p.q_scale;
+        if (FOLD == 3) {
+            // interleaved pairs (2i, 2i+1): even y = x*c - x'*s, odd y = x'*c + x*s (the skinny GEMM's rotary epilogue), then the scale
+            const float x0 = (rq.x - mean * gq.x) * rstd + cq.x, x1 = (rq.y - mean * gq.y) * rstd + cq.y;
+            const float x2 = (rq.z - mean * gq.z) * rstd + cq.z, x3 = (rq.w - mean * gq.w) * rstd + cq.w;
+            q4.x = (x0 * rcs.x - x1 * rcs.y) * p.q_scale; q4.y = (x1 * rcs.x + x0 * rcs.y) * p.q_scale;
+            q4.z = (x2 * rcs.z - x3 * rcs.w) * p.q_scale; q4.w = (x3 * rcs.z + x2 * rcs.w) * p.q_scale;
+        } else {
+            q4.x = ((rq.x - mean * gq.x) * rstd + cq.x) * p.q_scale; q4.y = ((rq.y - mean * gq.y) * rstd + cq.y) * p.q_scale;
+            q4.z = ((rq.z - mean * gq.z) * rstd + cq.z) * p.q_scale; q4.w = ((rq.w - mean * gq.w) * rstd + cq.w) * p.q_scale;
+        }
         if (FOLD == 2) {
             kn4.x = (rk.x - mean * gk.x) * rstd + ck.x; kn4.y = (rk.y - mean * gk.y) * rstd + ck.y;
             kn4.z = (rk.z - mean * gk.z) * rstd + ck.z; kn4.w = (rk.w - mean * gk.w) * rstd + ck.w;
@@ -333,6 +345,15 @@ int32_t amt_launch_attn_decode(const AttnDecodeParams& p, hipStream_t stream) {
                 case 32: launch_decode<32, 2>(p, stream); break;
                 case 64: launch_decode<64, 2>(p, stream); break;
                 case 128: launch_decode<128, 2>(p, stream); break;
+                default: AMT_CHECK_ARG(false, "attn_decode: head_dim %d not in {16,32,64,128}", p.hd);
+            }
+        } else if (p.rope) {
+            AMT_CHECK_ARG(p.rope_pos && p.rope_dim > 0 && p.rope_dim % 4 == 0, "attn_decode: bad rotary prologue");
+            switch (p.hd) {
+                case 16: launch_decode<16, 3>(p, stream); break;
+                case 32: launch_decode<32, 3>(p, stream); break;
+                case 64: launch_decode<64, 3>(p, stream); break;
+                case 128: launch_decode<128, 3>(p, stream); break;
                 default: AMT_CHECK_ARG(false, "attn_decode: head_dim %d not in {16,32,64,128}", p.hd);
             }
         } else {

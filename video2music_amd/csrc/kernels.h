@@ -89,6 +89,9 @@ struct AttnDecodeParams {
     float* xn; int ldq, d, new_kv; float eps, q_scale;
     float* k_new; float* v_new;   // the (writable) cache when new_kv
     unsigned long long* stamps;   // diagnostic builds only (-DAMT_STAMPS): [workgroup][8] s_memrealtime stamps; null in the library
+    // rotary embedding of the folded query (new_kv = 0 only): table [positions][rope_dim] of interleaved (cos, sin), the position in
+    // device memory; column n of the d_model-wide query uses entries (n % rope_dim) & ~1 and that + 1 (decode_gemm's rotary epilogue)
+    const float* rope; int rope_dim; const int* rope_pos;
 };
 int32_t amt_launch_attn_decode(const AttnDecodeParams& p, hipStream_t stream);
 

@@ -16,13 +16,16 @@
 
 namespace {
 
-constexpr int G_PTRS = 11, L_PTRS = 36;
+constexpr int G_PTRS = 11, L_PTRS = 40;
 enum { G_PR, G_PA, G_WKEY, G_CBIAS, G_ROPE, G_FNW, G_FNB, G_WOUT, G_BOUT, G_SLOT01, G_PE };
 enum { L_SAW, L_SAB, L_SAOW, L_SAOB, L_N1W, L_N1B, L_CAW, L_CAB, L_CAOW, L_CAOB, L_N2W, L_N2B, L_N3W, L_N3B,
        L_KC, L_VC, L_KX, L_VX, L_GATEW, L_GATEB, L_W1, L_B1, L_WG, L_BG, L_W2, L_B2, L_SW1, L_SB1, L_SWG, L_SBG, L_SW2, L_SB2,
        // stacked forms for the lockstep step: [gate of every expert (+ shared) | linear1 of every expert (+ shared)] as ONE packed
        // matrix and its bias; linear2 of every expert (+ shared) one after the other and their biases (null for a plain GLU layer)
-       L_GU, L_GUB, L_W2S, L_B2S };
+       L_GU, L_GUB, L_W2S, L_B2S,
+       // lockstep step, norm1 folded through the cross-attention's query projection (null: separate launches): packed
+       // [(Wq o gamma) Wo | Wq o gamma] (E x 2E), its bias (Wq o gamma) bo, g = rowsum(Wq o gamma), c = Wq beta + bq
+       L_G1P, L_G1B, L_FQG, L_FQC };
 
 // (root, attr) either as launch arguments or, for a captured step graph, from device memory (tok[0], tok[1])
 __global__ void embed_one_kernel(int root, int attr, const int* __restrict__ tok, float kv, const float* __restrict__ PR,
@@ -391,6 +394,21 @@ static int32_t v2_step_batch_impl(const void* const* tab, int32_t n_layers, int3
             if (pend_w) { cur = xa; pend_w = pend_b = nullptr; }
         }
         if ((rc = attn_rows(q, kc, vc, o, B, H, hd, max_seq, 0, pos, s))) return rc;
+        if (P(L_G1P) && fuse_ln && P(L_N1B)) {
+            // u = out-proj + residual AND the raw query product of norm1(u) in one launch; the cross-attention finishes the query
+            // (row statistics of u, rotary, scale) in its prologue and publishes norm1(u) as the residual of its out-projection
+            DecodeGemmParams g{};
+            g.B = B; g.eps = 1e-5f; g.scale = 1.f; g.x = o; g.ldx = E; g.x2 = cur; g.ldx2 = E; g.K1 = E; g.K = 2 * E;
+            g.Wp = P(L_SAOW); g.bias = P(L_SAOB); g.resid = cur; g.ldr = E; g.y = u; g.ldy = E;
+            g.n_split = E; g.N = 2 * E; g.Wp2 = P(L_G1P); g.bias2 = P(L_G1B); g.y2 = q; g.ldy2 = E;
+            if ((rc = amt_launch_decode_gemm(g, s))) return rc;
+            AttnDecodeParams a{};
+            a.k = P(L_KX); a.v = P(L_VX); a.o = o; a.B = B; a.H = H; a.hd = hd; a.cap = S; a.n_keys = S;
+            a.q = q; a.ldq = E; a.d = E; a.fold_u = u; a.fold_g = P(L_FQG); a.fold_c = P(L_FQC); a.fold_lnw = P(L_N1W); a.fold_lnb = P(L_N1B);
+            a.xn = xb; a.eps = 1e-5f; a.q_scale = qscale; a.rope = rope; a.rope_dim = E; a.rope_pos = pos;
+            if ((rc = amt_launch_attn_decode(a, s))) return rc;
+            cur = xb; pend_w = pend_b = nullptr;
+        } else {
         if ((rc = lin_rows(o, P(L_SAOW), P(L_SAOB), cur, u, B, E, E, s))) return rc;           // u = out-proj + residual
         cur = u; pend_w = P(L_N1W); pend_b = P(L_N1B);
         // ---- cross-attention: [norm1 ->] query projection -> rotary, scale ----
@@ -403,6 +421,7 @@ static int32_t v2_step_batch_impl(const void* const* tab, int32_t n_layers, int3
             if (pend_w) { cur = xb; pend_w = pend_b = nullptr; }
         }
         if ((rc = attn_rows(q, P(L_KX), P(L_VX), o, B, H, hd, S, S, nullptr, s))) return rc;      // [B][H][S][hd]
+        }
         if ((rc = lin_rows(o, P(L_CAOW), P(L_CAOB), cur, y, B, E, E, s))) return rc;
         cur = y; pend_w = P(L_N2W); pend_b = P(L_N2B);
         // ---- feed-forward: [norm2 ->] gate projection; up projection; down projection with the gate applied in its prologue ----

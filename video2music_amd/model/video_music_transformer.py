@@ -940,6 +940,28 @@ class VideoMusicTransformer_V2(nn.Module):
                         add(None)
                 for t in stacked(list(ff.experts) + ([ff.shared_expert] if ff.shared else []), True):
                     add(t)
+            # out-projection of the self-attention and the cross-attention's query projection in ONE launch of the lockstep step,
+            # norm1 folded through the projection (the base model's G1): with u = x + o Wo^T + bo the query is
+            # LayerNorm(u) Wq^T + bq = ((u (Wq o gamma)^T) - mean g) rstd + c, and u (Wq o gamma)^T = [o | x] [Wq' Wo | Wq']^T + Wq' bo.
+            # The launch produces u and that raw product; the attention kernel finishes the query with u's row statistics.
+            if isinstance(lyr.norm1, nn.LayerNorm) and 2 * E <= 1536 and os.environ.get("AMT_V2_FOLD_G1", "1") != "0":
+                from .. import ops
+                srcs = (sa.out_proj.weight, sa.out_proj.bias, ca.in_proj_weight, ca.in_proj_bias, lyr.norm1.weight, lyr.norm1.bias)
+                sig = tuple((t.data_ptr(), t._version) for t in srcs) + ("g1fold",)
+                cache = self.__dict__.setdefault("_pack_cache", {})
+                if sig not in cache:
+                    Wo, bo, Wq, bq = sa.out_proj.weight.detach(), sa.out_proj.bias.detach(), ca.in_proj_weight.detach()[:E], ca.in_proj_bias.detach()[:E]
+                    gamma, beta = lyr.norm1.weight.detach(), lyr.norm1.bias.detach()
+                    Wqg = (Wq * gamma.unsqueeze(0)).contiguous()                              # Wq o gamma
+                    A = ops.linear(Wqg, Wo.t().contiguous())                                   # (Wq o gamma) Wo
+                    P2 = torch.cat([A, Wqg], dim=1).contiguous()                               # (E, 2E)
+                    cache[sig] = [packed(P2), ops.linear(bo.view(1, E).contiguous(), Wqg).view(E).contiguous(),
+                                  Wqg.sum(dim=1).contiguous(), (ops.linear(beta.view(1, E).contiguous(), Wq.contiguous()).view(E) + bq).contiguous(), P2]
+                for t in cache[sig][:4]:
+                    add(t)
+            else:
+                for _ in range(4):
+                    add(None)
             widths.add(layer_dff)
             dff = layer_dff
         st["tab"] = (C.c_void_p * len(ptrs))(*ptrs)
