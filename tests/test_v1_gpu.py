@@ -135,3 +135,26 @@ def test_v1_options_vs_reference_golden(golden):
     """dropTokenRate, forward(mask=False), beam=2 / beam_chance=0.5 of the reference V1 class ('1.1') -- tests/golden/g_opts.npz."""
     from tests.test_v2_gpu import check_family_options
     check_family_options(golden, "v11", build("1.1"), lambda **over: build("1.1", **over))
+
+
+def test_lockstep_at_bench_width_equals_per_clip_generate():
+    """The lockstep step at the width the V2 bench runs (d_model 512, d_ff 1024, 32 clips): there its wide products take the
+    several-tiles-per-workgroup kernels (stacked gate|up matrix, grouped down projections) and the self-attention out-projection
+    rides with the folded cross-attention query projection; clip by clip the ids must still equal `generate` on that clip alone
+    (one-call step with device-routed experts, separate launches)."""
+    from tests.helpers import CFG_V2
+    from video2music_amd.model.video_music_transformer import VideoMusicTransformer_V2
+    B, T = 32, 20
+    m = VideoMusicTransformer_V2(**dict(CFG_V2, version_name="2.2", n_layers=4, num_heads=8, d_model=512, dim_feedforward=1024)).eval()
+    shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=0, recipe="feedback").items()})
+    m = m.cuda()
+    f = {k: v.cuda() for k, v in feats_t(synthetic.synthetic_features(B, seed=78)).items()}
+    pr = (torch.tensor([1]), torch.tensor([1]), torch.tensor([0]))
+    with torch.no_grad():
+        got = m.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], *pr, target_seq_length=T, beam=0, sampler="argmax")
+        assert len(set(got[:, 1:].flatten().tolist())) >= 8
+        for c in (0, 13, 31):
+            one = m.generate(f["semantic"][c:c + 1], f["key"][c], f["scene_offset"][c:c + 1], f["motion"][c:c + 1], f["emotion"][c:c + 1],
+                             *pr, target_seq_length=T, beam=0, sampler="argmax", decision="host")
+            assert torch.equal(one[0], got[c]), c

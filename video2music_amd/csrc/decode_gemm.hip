@@ -369,11 +369,18 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_wide_kernel(DecodeGemmPar
     if (grp * NTW >= n_tiles) return;               // the grid is padded to whole sets of 8 groups (uniform per workgroup)
     const int nt0 = grp * NTW, m0 = (((int)blockIdx.x >> 3) % mb) * MT;
     const int kt0 = wave * KCH;
+    const int zg = p.n_groups > 1 ? (int)blockIdx.y : 0;       // grouped launch: one expert per blockIdx.y
     const int r = m0 + wave, rc = min(r, p.B - 1);
-    const float* xr = p.x + (size_t)rc * p.ldx;
+    const float* xr = p.x + (size_t)zg * p.x_group_off + (size_t)rc * p.ldx;
     float4 v[KCH];
 #pragma unroll
     for (int c = 0; c < KCH; ++c) v[c] = ld4(xr + (c * 64 + lane) * 4);
+    float4 gv[PRO == 3 ? KCH : 1];
+    if (PRO == 3) {
+        const float* gr = p.glu_gate + (size_t)zg * p.x_group_off + (size_t)rc * p.ldx;
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) gv[c] = ld4(gr + (c * 64 + lane) * 4);
+    }
     float4 g0[PRO == 1 ? KCH : 1], h0[PRO == 1 ? KCH : 1];
     if (PRO == 1) {
 #pragma unroll
@@ -385,7 +392,7 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_wide_kernel(DecodeGemmPar
     float4 wt[NTW][KCH];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
-        const float* wbase = p.Wp + (size_t)min(nt0 + j, n_tiles - 1) * kt_n * 256;      // surplus tiles repeat the last one
+        const float* wbase = p.Wp + (size_t)zg * p.sel_w_stride + (size_t)min(nt0 + j, n_tiles - 1) * kt_n * 256;      // surplus tiles repeat the last one
 #pragma unroll
         for (int i = 0; i < KCH; ++i) wt[j][i] = ld4(wbase + ((size_t)(kt0 + i) * 64 + lane) * 4);
     }
@@ -406,6 +413,14 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_wide_kernel(DecodeGemmPar
             v[c].z = (v[c].z - mean) * rstd * g0[c].z + h0[c].z; v[c].w = (v[c].w - mean) * rstd * g0[c].w + h0[c].w;
         }
     }
+    if (PRO == 3) {
+        const float um = p.glu_only ? 0.f : 1.f, uo = p.glu_only ? 1.f : 0.f;      // h = u * silu(g), or silu(g) alone
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            v[c].x = (v[c].x * um + uo) * (gv[c].x / (1.0f + __expf(-gv[c].x))); v[c].y = (v[c].y * um + uo) * (gv[c].y / (1.0f + __expf(-gv[c].y)));
+            v[c].z = (v[c].z * um + uo) * (gv[c].z / (1.0f + __expf(-gv[c].z))); v[c].w = (v[c].w * um + uo) * (gv[c].w / (1.0f + __expf(-gv[c].w)));
+        }
+    }
 #pragma unroll
     for (int c = 0; c < KCH; ++c) st4(xs + wave * LD + (c * 64 + lane) * 4, v[c]);
     __syncthreads();
@@ -420,7 +435,7 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_wide_kernel(DecodeGemmPar
     for (int q = 0; q < JN; ++q) {
         const int j = jg + 4 * q, n = (nt0 + j) * 16 + (el & 15);
         const bool live = j < NTW && row < p.B && n < p.N;
-        e_bias[q] = *((live && p.bias) ? p.bias + n : p.zero);
+        e_bias[q] = *((live && p.bias) ? p.bias + (size_t)zg * p.sel_b_stride + n : p.zero);
         e_res[q] = *((live && p.resid) ? p.resid + (size_t)row * p.ldr + n : p.zero);
         if (PRO == 1 && p.xn && j < NTW && (nt0 + j) * 16 < K) {
             const int rr = e >> 4, c = e & 15;
@@ -464,7 +479,7 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_wide_kernel(DecodeGemmPar
                 if (n < p.scale_cols) val *= p.scale;
                 val += e_res[q];
                 if (p.relu) val = fmaxf(val, 0.f);
-                p.y[(size_t)row * p.ldy + n] = val;
+                p.y[(size_t)zg * p.y_group_off + (size_t)row * p.ldy + n] = val;
             }
         }
     }
@@ -488,7 +503,7 @@ int32_t launch_wide(const DecodeGemmParams& p, hipStream_t stream) {
     const size_t lr = (size_t)NTW * NW * 256 * sizeof(float);
     if (lds < lr) lds = lr;
     const int groups8 = cdiv(cdiv(cdiv(p.N, 16), NTW), 8) * 8;
-    hipLaunchKernelGGL((decode_gemm_wide_kernel<KCH, PRO, NTW>), dim3(groups8 * cdiv(p.B, MT)), dim3(NW * 64), lds, stream, p);
+    hipLaunchKernelGGL((decode_gemm_wide_kernel<KCH, PRO, NTW>), dim3(groups8 * cdiv(p.B, MT), p.n_groups > 1 ? p.n_groups : 1), dim3(NW * 64), lds, stream, p);
     AMT_LAUNCH_CHECK();
     return 0;
 }
@@ -551,6 +566,14 @@ int32_t amt_launch_decode_gemm(const DecodeGemmParams& p_in, hipStream_t stream)
     else AMT_CHECK_ARG(!p.ln_w || (!p.x2 && p.K <= 1024), "decode_gemm: the LayerNorm prologue takes a single source of K <= 1024");
     AMT_CHECK_ARG(!p.ln2_w || (p.ln_w && p.ln_b && p.ln2_b && p.pro == 0 && !p.glu_gate), "decode_gemm: the second LayerNorm follows a first one");
     // wide plain products: several column tiles per workgroup (see decode_gemm_wide_kernel)
+    // the grouped down projections of a mixture layer (gated prologue): more workgroups than the chip holds at once with one
+    // tile each, one round with two
+    static int wide_grp = -1;
+    if (wide_grp < 0) { const char* e = getenv("AMT_WIDE_GROUPED"); wide_grp = e ? atoi(e) : 1; }
+    if (wide_grp > 0 && p.n_groups > 1 && p.glu_gate && !p.ln_w && p.pro == 0 && !p.rope && !p.x2 && p.mode == 0 && p.ldw == 0 && !p.sel &&
+        (p.K == 512 || p.K == 1024) && cdiv(p.N, 16) * cdiv(p.B, MT) * p.n_groups > 256) {
+        return p.K == 512 ? launch_wide<2, 3, 2>(p, stream) : launch_wide<4, 3, 2>(p, stream);
+    }
     static int wide_ntw = -1;
     if (wide_ntw < 0) { const char* e = getenv("AMT_WIDE_NTW"); wide_ntw = e ? atoi(e) : 4; }
     if (wide_ntw > 0 && p.N >= 4096 && !p.x2 && p.n_split == 0 && !p.sel && p.n_groups <= 1 && p.mode == 0 && !p.rope && !p.glu_gate && p.pro == 0 &&
