@@ -24,7 +24,9 @@ namespace {
 constexpr int QB = 128;      // query rows per workgroup
 constexpr int KT = 32;       // keys per tile
 
-template <int HD, bool RPR>
+// NOMASK: relative positions WITHOUT the causal mask (forward(mask=False)); a separate instantiation so that the causal kernel
+// of the hot path keeps its exact instruction stream
+template <int HD, bool RPR, bool NOMASK = false>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     constexpr int LD = HD + 4;
     constexpr int NS = HD / 8;           // ds_read_b128 k-groups per operand row
@@ -130,9 +132,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
         // Without the causal mask (forward(mask=False), model/video_music_transformer.py:978-982) the tiles above the
         // diagonal are visible too; `_skew` (model/rpr.py:439-455) leaves the relative term ZERO for every key j > i, so those
         // tiles (k < 0) and the upper half of the diagonal tile (k == 0, distance < 0) take the plain Q.K score.
-        if constexpr (RPR) if (i0 >= j0) {
+        if constexpr (RPR) if (!NOMASK || i0 >= j0) {
             const int k = (i0 - j0) / 32;
-            const bool upper0 = !p.causal && k == 0;
             // The Er rows of a chunk come straight from L2 (the table is shared by every clip and head).  The rows of the NEXT
             // tile's chunk (k-2) are requested as soon as this tile's fragments are in the matrix pipe, so their latency
             // overlaps the softmax and the PV product instead of stalling the next tile.
@@ -173,7 +174,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
                 const int dlt = li - krow;                  // distance - D
                 const int c = dlt >= 0 ? k : k - 1;
                 const float r = scr[(c & 1) * (32 * 33) + li * 33 + (dlt & 31)];
-                sacc[e] += (upper0 && dlt < 0) ? 0.f : r;
+                if constexpr (NOMASK) sacc[e] += (k == 0 && dlt < 0) ? 0.f : r;
+                else sacc[e] += r;
             }
         }
 
@@ -386,7 +388,8 @@ int32_t launch_hd(const AttnParams& p, hipStream_t stream) {
         hipLaunchKernelGGL((attn_prefill_splitk_kernel<(HD <= 64 ? HD : 64)>), dim3(cdiv(p.Lq, 32) * p.H * p.B), dim3(256), 0, stream, p);
         return 0;
     }
-    if (p.Er) hipLaunchKernelGGL((attn_prefill_kernel<HD, true>), grid, dim3(256), 0, stream, p);
+    if (p.Er && !p.causal) hipLaunchKernelGGL((attn_prefill_kernel<HD, true, true>), grid, dim3(256), 0, stream, p);
+    else if (p.Er) hipLaunchKernelGGL((attn_prefill_kernel<HD, true>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((attn_prefill_kernel<HD, false>), grid, dim3(256), 0, stream, p);
     return 0;
 }
