@@ -13,6 +13,8 @@
 // and k0+4+e (h=1) -- any pairing is legal as long as A and B use the same one.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "amt_common.h"
 #include "kernels.h"
 
@@ -48,7 +50,12 @@ __device__ __forceinline__ void store_out(const GemmParams& p, int row, int col,
     }
 }
 
-template <int TM, int TN>
+// GATHER: rows of A come through an index (mixture-of-experts plan).  The dense instantiation has NO guarded load: rows / columns
+// past the edge read a clamped address (their results are never stored), because a load under a branch -- or behind the wait for
+// a gather index -- makes the compiler drain every outstanding load (s_waitcnt vmcnt(0)) in the middle of the k loop.
+// PF: prefetch distance in k-tiles (1: the tile stored to LDS at the end of an iteration was requested at its top; 2: a whole
+// iteration earlier, through a second register stage)
+template <int TM, int TN, bool GATHER = false, int PF = 2>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     constexpr int BM = 64 * TM, BN = 64 * TN, BMAX = BM > BN ? BM : BN;
     __shared__ __attribute__((aligned(16))) float lds[2][2][BMAX * LDS_LD];   // [buf][A|W][row][k]
@@ -74,26 +81,32 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 
     // staging: 256 threads x (rows/32) passes x float4 cover a rows x 32 tile (8 float4 per row)
     const int srow = tid >> 3, scol = (tid & 7) * 4;
-    float4 ra[2 * TM], rw[2 * TN];
-    auto gload = [&](int k0) {
+    // two register stages: the k-tile stored to LDS in an iteration was requested a whole iteration earlier (prefetch distance 2),
+    // so the LDS store never waits for global memory behind a single k-tile of MFMA work
+    float4 ra[2][2 * TM], rw[2][2 * TN];
+    // row pointers, fixed for the whole k loop (gather indices are read once, here); out-of-range rows alias row 0 / the last row
+    const float* arow[2 * TM];
+    const float* wrow[2 * TN];
 #pragma unroll
-        for (int i = 0; i < 2 * TM; ++i) {
-            const int gm = m0 + srow + i * 32;
-            int am = gm;
-            if (p.a_gather) am = (gm < p.M) ? p.a_gather[gm] : -1;
-            ra[i] = (gm < p.M && am >= 0) ? ld4(p.A + (size_t)am * p.lda + k0 + scol) : make_float4(0, 0, 0, 0);
-        }
+    for (int i = 0; i < 2 * TM; ++i) {
+        const int gm = min(m0 + srow + i * 32, p.M - 1);
+        int am = gm;
+        if (GATHER) am = max(p.a_gather[gm], 0);     // -1 = padding slot of the plan: any row, its product is never combined
+        arow[i] = p.A + (size_t)am * p.lda + scol;
+    }
 #pragma unroll
-        for (int i = 0; i < 2 * TN; ++i) {
-            const int gn = n0 + srow + i * 32;
-            rw[i] = (gn < p.N) ? ld4(p.W + (size_t)gn * p.ldw + k0 + scol) : make_float4(0, 0, 0, 0);
-        }
+    for (int i = 0; i < 2 * TN; ++i) wrow[i] = p.W + (size_t)min(n0 + srow + i * 32, p.N - 1) * p.ldw + scol;
+    auto gload = [&](int k0, int st) {
+#pragma unroll
+        for (int i = 0; i < 2 * TM; ++i) ra[st][i] = ld4(arow[i] + k0);
+#pragma unroll
+        for (int i = 0; i < 2 * TN; ++i) rw[st][i] = ld4(wrow[i] + k0);
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, int st) {
 #pragma unroll
-        for (int i = 0; i < 2 * TM; ++i) st4(&lds[buf][0][(srow + i * 32) * LDS_LD + scol], ra[i]);
+        for (int i = 0; i < 2 * TM; ++i) st4(&lds[buf][0][(srow + i * 32) * LDS_LD + scol], ra[st][i]);
 #pragma unroll
-        for (int i = 0; i < 2 * TN; ++i) st4(&lds[buf][1][(srow + i * 32) * LDS_LD + scol], rw[i]);
+        for (int i = 0; i < 2 * TN; ++i) st4(&lds[buf][1][(srow + i * 32) * LDS_LD + scol], rw[st][i]);
     };
 
     f32x16 acc[TM][TN];
@@ -106,12 +119,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 
     const int fr = lane & 31, fh = lane >> 5;
     const int nk = p.K / BK;
-    gload(0);
-    lstore(0);
+    gload(0, 0);
+    if (PF == 2) gload(min(1, nk - 1) * BK, 1);
+    lstore(0, 0);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
+    // (two iterations per trip so that the register stage is a compile-time index)
+    auto body = [&](int kt, auto stage) {
+        constexpr int ST = decltype(stage)::value;       // stage that holds k-tile kt + 1; k-tile kt + 2 goes into the other
         const int cur = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * BK);
+        gload(min(kt + PF, nk - 1) * BK, PF == 2 ? ST ^ 1 : 0);          // unconditional (the last two trips re-read the last k-tile): a guarded
+                                                         // load hides the number of loads in flight and every wait becomes vmcnt(0)
         const float* la = &lds[cur][0][(wr * 32 * TM + fr) * LDS_LD + fh * 4];
         const float* lw = &lds[cur][1][(wc * 32 * TN + fr) * LDS_LD + fh * 4];
 #pragma unroll
@@ -133,9 +150,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                     }
         }
         if (kt + 1 < nk) {
-            lstore(cur ^ 1);
+            lstore(cur ^ 1, PF == 2 ? ST : 0);
             __syncthreads();
         }
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        body(kt, std::integral_constant<int, 1>{});
+        if (kt + 1 < nk) body(kt + 1, std::integral_constant<int, 0>{});
     }
 
     // ---- epilogue ----
@@ -245,15 +266,26 @@ int32_t amt_launch_gemm(const GemmParams& p, hipStream_t stream) {
         return amt_launch_decode_gemm(g, stream);
     }
     // 64x64 tiles (one accumulator per wave, four times the workgroups) measure faster than 128x128 on every shape of this
-    // model (K <= 1312: 103-110 vs 98-104 TFLOP/s at M = 32768, 85-100 vs 61-86 at M = 9600, 19 vs 50 us for a single tile row);
-    // the big tile only wins for long-K products with many tiles (4096^3: 109 vs 103).
+    // model (K <= 1312; 114-126 TFLOP/s at M = 32768, 111 at M = 9600 since the loads of the k loop are branch-free and two
+    // k-tiles ahead: tools/bench_gemm.py; 103-110 before); the big tile is kept for long-K products with many tiles.
     const int t128 = cdiv(p.M, 128) * cdiv(p.N, 128);
     static int t64_below = -1;
     if (t64_below < 0) { const char* e = getenv("AMT_GEMM_T64_BELOW"); t64_below = e ? atoi(e) : 768; }
-    if (t128 >= t64_below && p.K >= 2048)
-        hipLaunchKernelGGL((gemm_f32_kernel<2, 2>), dim3(t128), dim3(256), 0, stream, p);
-    else
-        hipLaunchKernelGGL((gemm_f32_kernel<1, 1>), dim3(cdiv(p.M, 64) * cdiv(p.N, 64)), dim3(256), 0, stream, p);
+    static int pf = -1;
+    if (pf < 0) { const char* e = getenv("AMT_GEMM_PF"); pf = e ? atoi(e) : 22; }      // tens: big tile, units: small tile
+    const bool big = t128 >= t64_below && p.K >= 2048;
+    const dim3 g64(cdiv(p.M, 64) * cdiv(p.N, 64));
+    if (p.a_gather) {
+        if (big) hipLaunchKernelGGL((gemm_f32_kernel<2, 2, true, 1>), dim3(t128), dim3(256), 0, stream, p);
+        else if (pf % 10 == 2) hipLaunchKernelGGL((gemm_f32_kernel<1, 1, true, 2>), g64, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_f32_kernel<1, 1, true, 1>), g64, dim3(256), 0, stream, p);
+    } else if (big) {
+        if (pf / 10 == 2) hipLaunchKernelGGL((gemm_f32_kernel<2, 2, false, 2>), dim3(t128), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_f32_kernel<2, 2, false, 1>), dim3(t128), dim3(256), 0, stream, p);
+    } else {
+        if (pf % 10 == 2) hipLaunchKernelGGL((gemm_f32_kernel<1, 1, false, 2>), g64, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_f32_kernel<1, 1, false, 1>), g64, dim3(256), 0, stream, p);
+    }
     AMT_LAUNCH_CHECK();
     return 0;
 }
