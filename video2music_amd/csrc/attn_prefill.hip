@@ -76,16 +76,19 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
 
     // K/V tile staging: 32 rows x HD/4 float4 per tensor over 256 threads
     constexpr int F4_ROW = HD / 4, F4_TILE = KT * F4_ROW, PER_T = (F4_TILE + 255) / 256;
+    static_assert(F4_TILE % 256 == 0, "a K/V tile is a whole number of 256-thread passes");
     float4 kst[PER_T], vst[PER_T];
     auto gload = [&](int j0) {
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) {
             const int f = tid + i * 256;
             const int r = f / F4_ROW, c = (f - r * F4_ROW) * 4;
-            const int j = j0 + r;
-            const bool ok = (f < F4_TILE) && (j < p.Lk);
-            kst[i] = ok ? ld4(kp + (size_t)j * p.k_ls + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            vst[i] = ok ? ld4(vp + (size_t)j * p.v_ls + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            // no guarded load: keys past the end re-read the last row (their scores are masked to -inf, so P = 0 meets a finite
+            // V row); a load under a branch hides the number of loads in flight from the compiler, which then drains them all
+            // (s_waitcnt vmcnt(0)) in front of the relative-position prefetch
+            const int j = min(j0 + r, p.Lk - 1);
+            kst[i] = ld4(kp + (size_t)j * p.k_ls + c);
+            vst[i] = ld4(vp + (size_t)j * p.v_ls + c);
         }
     };
     auto lstore = [&]() {
@@ -291,10 +294,9 @@ __global__ __launch_bounds__(256) void attn_prefill_splitk_kernel(AttnParams p) 
         for (int i = 0; i < PER_W; ++i) {
             const int f = lane + i * 64;
             const int r = f / F4_ROW, c = (f - r * F4_ROW) * 4;
-            const int j = j0 + r;
-            const bool ok = j < p.Lk;
-            kst[i] = ok ? ld4(kp + (size_t)j * p.k_ls + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            vst[i] = ok ? ld4(vp + (size_t)j * p.v_ls + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int j = min(j0 + r, p.Lk - 1);          // (unguarded: see attn_prefill_kernel)
+            kst[i] = ld4(kp + (size_t)j * p.k_ls + c);
+            vst[i] = ld4(vp + (size_t)j * p.v_ls + c);
         }
     };
     if (wave < n_tiles) gload(wave * KT);
