@@ -11,7 +11,7 @@ with open(f) as fh:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0],
                      r.get("Grid_Size_X", r.get("Grid_Size", ""))))
 rows.sort()
-cuts = [i for i, r in enumerate(rows) if "v2_decide_kernel" in r[2]]
+cuts = [i for i, r in enumerate(rows) if "v2_decide" in r[2]]
 steps = [rows[cuts[i] + 1: cuts[i + 1] + 1] for i in range(len(cuts) - 1)]
 n = int(np.median([len(s) for s in steps]))
 steps = [s for s in steps if len(s) == n]
