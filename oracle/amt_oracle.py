@@ -432,15 +432,16 @@ def glu_expert(x, sd, p):
     return linear(a * gte, sd[p + "linear2.weight"], sd[p + "linear2.bias"])
 
 
-def moe_forward(x, sd, n_experts, k=2, shared=False, routing=None):
+def moe_forward(x, sd, n_experts, k=2, shared=False, routing=None, temperature=1.0):
     """model/moe.py:167-200 (MoELayer) / :231-302 (SharedMoELayer), eval mode, Appendix A6.
 
     gate logits -> top-k -> softmax over the k logits (fp32) -> sum_e w_e * expert_e(x), accumulated
-    in expert-index order; shared: + shared_expert(x)/k.  ``routing`` (dict) receives idx / weights.
+    in expert-index order; shared: + shared_expert(x)/k.  ``routing`` (dict) receives idx / weights.  ``temperature``: the value
+    SharedMoELayer's scheduler holds after its step of this forward (:238-240), dividing the k logits (:288).
     """
     logits = linear(x, sd["gate.weight"], sd.get("gate.bias"))
     w, idx = torch.topk(logits, k, dim=-1)
-    w = torch.softmax(w.float(), dim=-1).to(x.dtype)
+    w = torch.softmax(w.float() / temperature, dim=-1).to(x.dtype)
     out = torch.zeros_like(x)
     for e in range(n_experts):
         sel = idx == e                                          # (..., k)

@@ -13,6 +13,8 @@ VERDICT r1 "missing" item 5; none of them has a caller in the reference, the fix
   * dropTokenRate of the V1 / V2 / V3 classes (:193-197, 488-492, 798-802): rows of the video stream zeroed by
     `torch.rand(B, S) > rate`, also in eval mode and anew in every forward of a generate; torch.manual_seed before the call pins
     the masks.  The same classes with mask=False and with the top-k branch (beam=2, beam_chance=0.5).
+  * SharedMoELayer(temperature_scheduler=...) (model/moe.py:238-240, 288): the scheduler steps in every forward, eval included,
+    and the two routing logits are divided by its temperature before their softmax.
 -> tests/golden/g_opts.npz"""
 import os
 import random
@@ -150,6 +152,18 @@ def main():
             Categorical.sample = orig
         out[f"{tag}_beam2_c05_min_gap"] = np.array(min(gaps))
         print(tag, "beam2/0.5", out[f"{tag}_beam2_c05"].shape, "min rel gap", min(gaps), flush=True)
+    # ---- SharedMoELayer with a temperature scheduler: stepped in every forward, eval included (moe.py:238-240, 288) ----
+    rs2 = np.random.RandomState(31)
+    xm = rs2.standard_normal((16, 3, 128)).astype(np.float32)
+    sched = ref.moe.TemperatureScheduler(temperature_min=0.7, temperature_max=0.9, temperature_step=0.15)
+    layer = ref.moe.SharedMoELayer(ref.moe.GLUExpert(128, 256), 128, n_experts=8, n_experts_per_token=2, balancing=True,
+                                   temperature_scheduler=sched).eval()
+    MG.load_synthetic(layer, seed=5)
+    out["moe_t_x"] = xm
+    for call in range(3):                        # t = 0.85, 0.9 (clamped), 0.9
+        out[f"moe_t_y{call}"] = layer(t(xm)).numpy()
+        out[f"moe_t_t{call}"] = np.array(sched.getT())
+    print("temperature scheduler", [float(out[f"moe_t_t{c}"]) for c in range(3)], flush=True)
     np.savez_compressed(os.path.join(MG.OUT, "g_opts.npz"), **out)
     print("wrote g_opts.npz")
 

@@ -174,17 +174,24 @@ def test_user_primer_chords_follow_the_reference_rules():
     assert a.primer == "C Am" and a.num_prime_chord == 30 and not a.primer_from_dataset
 
 
-def test_moe_schedulers_follow_the_reference_or_refuse():
+def test_moe_schedulers_follow_the_reference():
     """moe.py:160-179: MoELayer's schedulers act in training only (kept, no effect here); SharedMoELayer's temperature
-    scheduler divides the routing weights in eval too (:238-240,288) — refused rather than silently ignored."""
+    scheduler steps in eval too and divides the routing logits (:238-240,288)."""
     from video2music_amd.model.moe import GLUExpert, MoELayer, SharedMoELayer
     sched = object()
     a = MoELayer(GLUExpert(16, 32), 16, topk_scheduler=sched, temperature_scheduler=sched)
     assert a.topk_scheduler is sched and a.temperature_scheduler is sched
     b = SharedMoELayer(GLUExpert(16, 32), 16, topk_scheduler=sched)
     assert b.topk_scheduler is sched
-    with pytest.raises(NotImplementedError, match="temperature"):
-        SharedMoELayer(GLUExpert(16, 32), 16, temperature_scheduler=sched)
+    from video2music_amd.model.moe import TemperatureScheduler, TopKScheduler
+    ts = TemperatureScheduler(temperature_min=0.7, temperature_max=0.9, temperature_step=0.15)
+    c = SharedMoELayer(GLUExpert(16, 32), 16, temperature_scheduler=ts)
+    assert [round(c._temperature(), 6) for _ in range(3)] == [0.85, 0.9, 0.9] and b._temperature() == 1.0 and a._temperature() == 1.0
+    k = TopKScheduler(n_experts=4, min_n_experts_per_token=2, update_step=2)
+    ks = []
+    for _ in range(6):
+        k.step(); ks.append(k.getK())
+    assert ks == [4, 3, 3, 2, 2, 2]
 
 
 def test_v2_builds_three_shallow_layers_whatever_n_layers_says():

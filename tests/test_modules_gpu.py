@@ -179,3 +179,19 @@ def test_bench_line_contract(tmp_path):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert abs(d["value"] - 3 * 47 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-2
+
+
+def test_shared_moe_temperature_scheduler_vs_reference_golden(golden):
+    """SharedMoELayer(temperature_scheduler=...): stepped in every forward, eval included, the two routing logits divided by the
+    temperature before their softmax (reference model/moe.py:238-240, 288) -- three consecutive calls of the reference layer."""
+    from video2music_amd.model.moe import TemperatureScheduler
+    g = golden("g_opts.npz")
+    sched = TemperatureScheduler(temperature_min=0.7, temperature_max=0.9, temperature_step=0.15)
+    layer = SharedMoELayer(GLUExpert(128, 256), 128, n_experts=8, n_experts_per_token=2, balancing=True, temperature_scheduler=sched)
+    m, _ = load(layer, moe_shapes(8, 128, 256, True), 5)
+    x = torch.from_numpy(g["moe_t_x"]).cuda()
+    for c in range(3):
+        y = m(x)
+        assert abs(sched.getT() - float(g[f"moe_t_t{c}"])) < 1e-9
+        err = np.abs(y.cpu().numpy() - g[f"moe_t_y{c}"]).max()
+        assert err < 1e-4, (c, err)

@@ -325,3 +325,15 @@ def test_v2_drop_token_rate_and_no_mask(golden):
     assert np.array_equal(keep.numpy(), g["v22_drop_mask"])
     assert np.abs(O.forward_v2(*args, drop_keep=keep).numpy() - g["v22_drop_logits"]).max() < 1e-4       # fp32, logits of magnitude ~20
     assert np.abs(O.forward_v2(*args, mask=False).numpy() - g["v22_nomask_logits"]).max() < 1e-4
+
+
+def test_shared_moe_temperature_scheduler(golden):
+    """SharedMoELayer steps its temperature scheduler in eval mode too and divides the routing logits by it (moe.py:238-240, 288)."""
+    g = golden("g_opts.npz")
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(moe_shapes(8, 128, 256, True), seed=5).items()}
+    ts = [float(g[f"moe_t_t{c}"]) for c in range(3)]
+    assert abs(ts[0] - 0.85) < 1e-9 and abs(ts[1] - 0.9) < 1e-9 and abs(ts[2] - 0.9) < 1e-9
+    for c in range(3):
+        y = O.moe_forward(torch.from_numpy(g["moe_t_x"]), sd, 8, k=2, shared=True, temperature=ts[c])
+        assert np.abs(y.numpy() - g[f"moe_t_y{c}"]).max() < TOL
+    assert np.abs(g["moe_t_y0"] - g["moe_t_y1"]).max() > 1e-4

@@ -130,6 +130,41 @@ def _stack(mods, attr, field):
     return torch.stack([_slot_tensor(l, attr, field, width) for l in lins]).contiguous()
 
 
+class TopKScheduler(nn.Module):
+    """Reference ``TopKScheduler`` (model/moe.py:66-82): k falls from n_experts to the minimum, one per `update_step` calls.
+    The layers consult it in training mode only."""
+
+    def __init__(self, n_experts=8, min_n_experts_per_token=2, update_step=16):
+        super().__init__()
+        self.n_experts, self.min_n_experts_per_token, self.k = n_experts, min_n_experts_per_token, n_experts
+        self.update_step, self.counting_step = update_step, 0
+
+    def step(self):
+        self.counting_step += 1
+        if self.counting_step % self.update_step == 0:
+            self.k = max(self.min_n_experts_per_token, self.k - 1)
+
+    def getK(self):
+        return self.k
+
+
+class TemperatureScheduler(nn.Module):
+    """Reference ``TemperatureScheduler`` (model/moe.py:84-97): t climbs from temperature_min by temperature_step per call up to
+    temperature_max.  ``SharedMoELayer`` steps it in every forward, eval included (:238-240)."""
+
+    def __init__(self, temperature_min=0.8, temperature_max=1.1, temperature_step=0.0005):
+        super().__init__()
+        self.temperature_min, self.temperature_max, self.temperature_step = temperature_min, temperature_max, temperature_step
+        self.t = self.temperature_min
+
+    def step(self):
+        self.t += self.temperature_step
+        self.t = min(self.t, self.temperature_max)
+
+    def getT(self):
+        return self.t
+
+
 class _MoEBase(nn.Module):
     shared = False
     ep_group = None
@@ -150,6 +185,9 @@ class _MoEBase(nn.Module):
         idx = torch.empty(n_tok, 2, device=x.device, dtype=torch.int32)
         wts = torch.empty(n_tok, 2, device=x.device, dtype=torch.float32)
         gw, gb = self.gate.weight.detach().contiguous(), self.gate.bias.detach().contiguous()
+        t = self._temperature()
+        if t != 1.0:
+            gw, gb = (gw / t).contiguous(), (gb / t).contiguous()
         _lib.call("amt_moe_route_fwd", p(xf), p(gw), p(gb), p(idx), p(wts), n_tok, d, n_exp, st())
         world, rank = dist.get_world_size(self.ep_group), dist.get_rank(self.ep_group)
         e_local = n_exp // world
@@ -181,6 +219,10 @@ class _MoEBase(nn.Module):
         out = expert_parallel_moe(xf, idx, wts, n_exp, run_local, combine, self.ep_group)
         self.last_routing = (idx.view(L, B, 2), wts.view(L, B, 2))
         return out.view(L, B, d)
+
+    def _temperature(self):
+        """Routing temperature of this forward: 1 unless the layer steps a temperature scheduler in eval mode (SharedMoELayer)."""
+        return 1.0
 
     def _stacked_expert_weights(self):
         """(n_exp, ...) contiguous copies of the experts' tensors for the grouped GEMMs, rebuilt only when a
@@ -218,6 +260,11 @@ class _MoEBase(nn.Module):
         wts = torch.empty(n_tok, 2, device=x.device, dtype=torch.float32)
         scratch = torch.empty(_lib.call("amt_moe_scratch_floats", n_tok, d, dff, n_exp), device=x.device, dtype=torch.float32)
         gw, gb = self.gate.weight.detach().contiguous(), self.gate.bias.detach().contiguous()
+        t = self._temperature()
+        if t != 1.0:
+            # softmax(top-2 logits / t) (moe.py:288): the top-2 of logits / t are the top-2 of the logits, so the temperature is
+            # folded into the router's weight and bias
+            gw, gb = (gw / t).contiguous(), (gb / t).contiguous()
         _lib.call("amt_moe_fwd", p(xf), p(gw), p(gb), p(w1), p(b1), p(wg), p(bg), p(w2), p(b2),
                   *[p(t) for t in sh], p(out), p(idx), p(wts), p(scratch), n_tok, d, dff, n_exp, _lib.stream_ptr())
         self.last_routing = (idx.view(L, B, 2), wts.view(L, B, 2))
@@ -251,11 +298,8 @@ class SharedMoELayer(_MoEBase):
         super().__init__()
         if use_KAN:
             raise NotImplementedError("KAN gates need efficient_kan (absent); outside the hot path")
-        if temperature_scheduler is not None:
-            # moe.py:238-240,288: this class steps the temperature and divides the routing weights by it in eval mode too;
-            # the fused router has no temperature input, and silently ignoring it would route differently from the reference
-            raise NotImplementedError("SharedMoELayer(temperature_scheduler=...) changes eval-time routing weights "
-                                      "(reference moe.py:238-240,288); not built — no reference model passes one")
+        if temperature_scheduler is not None:   # stepped in EVERY forward, eval included (:238-240), and applied at :288
+            self.temperature_scheduler = temperature_scheduler
         if topk_scheduler is not None:          # training-only (:232-236)
             self.topk_scheduler = topk_scheduler
         self.n_experts, self.n_experts_per_token, self.d_model = n_experts, n_experts_per_token, d_model
@@ -267,6 +311,12 @@ class SharedMoELayer(_MoEBase):
             self.register_buffer("bias", torch.zeros((n_experts, 1)))
             self.update_rate = 0.001
         self.shared_expert = copy.deepcopy(expert)                                         # :229
+
+    def _temperature(self):
+        if hasattr(self, "temperature_scheduler"):
+            self.temperature_scheduler.step()
+            return float(self.temperature_scheduler.getT())
+        return 1.0
 
     def forward(self, x):
         return self._run(x)
