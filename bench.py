@@ -268,7 +268,7 @@ def roofline(model, f, prim, B, T, cfg):
     shape_ok = B == 32 and d == 512 and cfg["num_heads"] == 8
     traffic, traffic_src = pmc_traffic("self_attn", self_bytes, shape_ok)
     return {
-        "bound": "hbm", "kernel": "attn_decode_kernel<64, true, true, {0,2}> (relative-position self-attention, decode step; FOLD 2 in layers 1-5)",
+        "bound": "hbm", "kernel": "attn_decode_kernel<64, true, true, {0,2}, 2> (relative-position self-attention, decode step; FOLD 2 in layers 1-5)",
         "achieved": round(self_bytes / self_us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(self_bytes / self_us / 1e3 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
         "launches": n, "avg_launch_us": round(self_us, 3), "algorithmic_bytes_per_launch": round(self_bytes),
@@ -277,7 +277,7 @@ def roofline(model, f, prim, B, T, cfg):
         "generate_ms": {"full": round(full, 2), "without_self_attn": round(no_self, 2), "without_cross_attn": round(no_cross, 2)},
         "event_pair": dict(ev("self_attn_decode", self_bytes), empty_pair_us=round(empty_us, 2),
                            method="HIP event pair on the launch stream around every launch of an eager replay of one full generate"),
-        "cross_attn": {"kernel": "attn_decode_kernel<64, false, true, 1> (cross-attention over video K/V, decode step)",
+        "cross_attn": {"kernel": "attn_decode_kernel<64, false, true, 1, 2> (cross-attention over video K/V, decode step)",
                        "algorithmic_bytes_per_launch": round(cross_bytes), "avg_launch_us": round(cross_us, 3),
                        "achieved": round(cross_bytes / cross_us / 1e3, 1), "frac": round(cross_bytes / cross_us / 1e3 / HBM_PEAK_GBS, 4),
                        "traffic": pmc_traffic("cross_attn", cross_bytes, shape_ok)[0], "event_pair": ev("cross_attn_decode", cross_bytes)},

@@ -18,9 +18,9 @@ sa, ca = alg["self_algorithmic_bytes_per_launch"], alg["cross_algorithmic_bytes_
 out = {
     "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/gpu_pmc_attn.sh) of tools/pmc_attn.py: the decode-attention kernels of the shipped (LayerNorm-folded) step at the config-2 launch shape (B=32,H=8,hd=64), positions t=7,15,...,1023, six layer-sized K/V caches cycled",
     "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced stream -> traffic = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 bytes (counter unit KiB)",
-    "self_attn": ent(f, w, "attn_decode_kernel<64, true, true, 2>", sa),
-    "cross_attn": ent(f, w, "attn_decode_kernel<64, false, true, 1>", ca),
-    "plain_variant_same_method": {"self_attn": ent(fp, wp, "attn_decode_kernel<64, true, true, 0>", sa), "cross_attn": ent(fp, wp, "attn_decode_kernel<64, false, true, 0>", ca)},
+    "self_attn": ent(f, w, "attn_decode_kernel<64, true, true, 2, 2>", sa),
+    "cross_attn": ent(f, w, "attn_decode_kernel<64, false, true, 1, 2>", ca),
+    "plain_variant_same_method": {"self_attn": ent(fp, wp, "attn_decode_kernel<64, true, true, 0, 2>", sa), "cross_attn": ent(fp, wp, "attn_decode_kernel<64, false, true, 0, 2>", ca)},
     "kernel_source_sha256": hashlib.sha256(open(os.path.join(R, "video2music_amd", "csrc", "attn_decode.hip"), "rb").read()).hexdigest(),
     "round2_note": "re-collected after the last round-2 change of attn_decode.hip (tools/pmc_attn_json.py).  The PMC pass over the REAL decode step (profiles/r02_pmc_decode_step_FETCH_SIZE.json, bench.py --seq 192 under rocprofv3 --pmc FETCH_SIZE, an earlier source) gave 19555.6 KiB per cross-attention launch.  bench.py reports `traffic` from this file only while the sha256 of video2music_amd/csrc/attn_decode.hip matches kernel_source_sha256, null otherwise.",
 }

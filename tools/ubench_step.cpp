@@ -18,8 +18,9 @@ void amt_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vprint
 struct Launch { std::string name; int kind; DecodeGemmParams g; AttnDecodeParams a; int wgs; unsigned long long* stamps; };
 
 int main(int argc, char** argv) {
-    const int B = 32, d = 512, dff = 1024, H = 8, hd = 64, S = 300, cap = 1024, nl = 6;
+    const int B = 32, d = 512, dff = 1024, H = 8, hd = 64, S = 300, nl = 6;
     const int t = argc > 1 ? atoi(argv[1]) : 511;
+    const int cap = 1024 + (argc > 2 ? atoi(argv[2]) : 0);      // rows per (clip, head) of the self-attention cache: 1024 + padding
     auto falloc = [](size_t n) { float* p; CK(hipMalloc(&p, n * 4)); CK(hipMemset(p, 0, n * 4)); return p; };
     float *ob = falloc(B * d), *xa = falloc(B * d), *xb = falloc(B * d), *u1 = falloc(B * d), *u2 = falloc(B * d), *u3 = falloc(B * d);
     float *qraw = falloc(B * d), *hraw = falloc(B * dff), *qkvraw = falloc(B * 3 * d), *vecs = falloc(16384);

@@ -75,15 +75,19 @@ struct amt_handle {
     const float *pe = nullptr, *pe_v = nullptr;
     // encoder state of the last amt_encode
     int encB = 0, encS = 0;
-    float* KVx = nullptr;                // [2][nl][maxB][H][Scap][hd]
+    float* KVx = nullptr;                // [2][nl][maxB][H][kx_rows][hd]
     size_t kvx_layer = 0, kvx_part = 0;
     float* memory = nullptr;             // [maxB*Scap][d]
     // shared big workspaces (rows = maxB * max(Scap, Tcap))
     size_t ws_rows = 0;
     float *wsX = nullptr, *wsU = nullptr, *wsQKV = nullptr, *wsO = nullptr, *wsH = nullptr, *wsA0 = nullptr, *wsQc = nullptr;
     // decode state
-    float* KVc = nullptr;                // [2][nl][maxB][H][Tcap][hd]
+    float* KVc = nullptr;                // [2][nl][maxB][H][kv_rows][hd]
     size_t kvc_layer = 0, kvc_part = 0;
+    // rows per (clip, head) of the self-attention cache: Tcap made odd.  With Tcap = 1024 rows of 256 B the heads lie exactly
+    // 256 KiB apart and the 256 workgroups of a decode-attention launch, which all stream the same row range at the same time,
+    // camp on the same HBM channels: one padding row de-aliases them (in-kernel timeline of the step at t = 1023: 342 -> 309 us)
+    int kv_rows = 0, kx_rows = 0;     // (kx_rows: the same for the cross-attention K/V, Scap rows per head)
     float *x_in = nullptr, *u1 = nullptr, *u2 = nullptr, *u3 = nullptr, *xa = nullptr, *xb = nullptr, *xc = nullptr;
     float *qb = nullptr, *ob = nullptr, *hb = nullptr, *keyb = nullptr;
     bool fold = false;                   // decode chain with folded LayerNorms (5 kernels per layer instead of 8)
@@ -220,7 +224,7 @@ SampleParams sample_params(amt_handle* h, float* logits_out, float* probs_out, i
     if (h->fold) {
         p.lraw = h->lraw; p.ld_lraw = VS; p.h1 = h->vs; p.h2 = h->vs + VS; p.h3 = h->vs + 3 * VS; p.h4 = h->vs + 4 * VS;
         p.tab_r = h->tab_r; p.tab_a = h->tab_a; p.tab_k = h->tab_k; p.tab_p = h->tab_p;
-        p.q0 = h->qb; p.kc0 = h->KVc; p.vc0 = h->KVc + h->kvc_part; p.H = h->H; p.hd = h->hd; p.cap = h->Tcap;
+        p.q0 = h->qb; p.kc0 = h->KVc; p.vc0 = h->KVc + h->kvc_part; p.H = h->H; p.hd = h->hd; p.cap = h->kv_rows;
         p.q_scale = 1.0f / sqrtf((float)h->hd);
     }
     return p;
@@ -262,7 +266,7 @@ int32_t enqueue_decoder_step_folded(amt_handle* h, hipStream_t s, StepProf* prof
         const float* Kx = h->KVx + (size_t)l * h->kvx_layer;
         const float* Vx = Kx + h->kvx_part;
         AttnDecodeParams a{};
-        a.k = Kc; a.v = Vc; a.o = h->ob; a.B = B; a.H = H; a.hd = hd; a.cap = h->Tcap;
+        a.k = Kc; a.v = Vc; a.o = h->ob; a.B = B; a.H = H; a.hd = hd; a.cap = h->kv_rows;
         a.pos = h->pos; a.Er = L.Er; a.er_len = h->Tcap;
         if (l == 0) {
             a.q = h->qb;          // written, with this position's K/V rows, by the previous sampling head / embed_step (table sums)
@@ -286,7 +290,7 @@ int32_t enqueue_decoder_step_folded(amt_handle* h, hipStream_t s, StepProf* prof
         if ((rc = amt_launch_decode_gemm(g1, s))) return rc;
         PROF_END(2);
         AttnDecodeParams x{};
-        x.k = Kx; x.v = Vx; x.o = h->ob; x.B = B; x.H = H; x.hd = hd; x.cap = h->Scap; x.n_keys = h->encS;
+        x.k = Kx; x.v = Vx; x.o = h->ob; x.B = B; x.H = H; x.hd = hd; x.cap = h->kx_rows; x.n_keys = h->encS;
         x.q = h->qraw; x.ldq = d; x.d = d; x.fold_u = h->u1; x.fold_g = L.va; x.fold_c = L.va + d;
         x.fold_lnw = L.n1w; x.fold_lnb = L.n1b; x.xn = h->xb; x.eps = LN_EPS; x.q_scale = qscale;
         if (!(h->skip_mask & 2)) {
@@ -332,14 +336,14 @@ int32_t enqueue_decoder_step(amt_handle* h, hipStream_t s, StepProf* prof = null
         g.x = l == 0 ? h->x_in : h->u3; g.ldx = d; g.Wp = L.p_sa; g.bias = L.sa_b; g.N = 3 * d; g.K = d;
         if (l > 0) { g.ln_w = h->dec[l - 1].n3w; g.ln_b = h->dec[l - 1].n3b; g.xn = h->xa; }
         g.mode = 1; g.y = h->qb; g.ldy = d; g.scale = qscale; g.scale_cols = d;
-        g.kcache = Kc; g.vcache = Vc; g.H = H; g.hd = hd; g.cap = h->Tcap; g.pos = h->pos; g.d = d;
+        g.kcache = Kc; g.vcache = Vc; g.H = H; g.hd = hd; g.cap = h->kv_rows; g.pos = h->pos; g.d = d;
         PROF_BEGIN();
         if ((rc = amt_launch_decode_gemm(g, s))) return rc;
         PROF_END(2);
         const float* r0 = l == 0 ? h->x_in : h->xa;
         // K2: relative-position self-attention over the cache
         AttnDecodeParams a{};
-        a.q = h->qb; a.k = Kc; a.v = Vc; a.o = h->ob; a.B = B; a.H = H; a.hd = hd; a.cap = h->Tcap;
+        a.q = h->qb; a.k = Kc; a.v = Vc; a.o = h->ob; a.B = B; a.H = H; a.hd = hd; a.cap = h->kv_rows;
         a.pos = h->pos; a.Er = L.Er; a.er_len = h->Tcap;
         if (!(h->skip_mask & 1)) {
             PROF_BEGIN();
@@ -362,7 +366,7 @@ int32_t enqueue_decoder_step(amt_handle* h, hipStream_t s, StepProf* prof = null
         PROF_END(2);
         // K5: cross-attention over the clip's video keys
         AttnDecodeParams x{};
-        x.q = h->qb; x.k = Kx; x.v = Vx; x.o = h->ob; x.B = B; x.H = H; x.hd = hd; x.cap = h->Scap; x.n_keys = h->encS;
+        x.q = h->qb; x.k = Kx; x.v = Vx; x.o = h->ob; x.B = B; x.H = H; x.hd = hd; x.cap = h->kx_rows; x.n_keys = h->encS;
         if (!(h->skip_mask & 2)) {
             PROF_BEGIN();
             if ((rc = amt_launch_attn_decode(x, s))) return rc;
@@ -548,10 +552,13 @@ extern "C" int32_t amt_finalize(amt_handle* h) {
     }
 
     if (!h->KVx) {   // first finalize: allocate the persistent state
-        h->kvx_part = (size_t)h->nl * h->maxB * h->H * h->Scap * h->hd;
-        h->kvx_layer = (size_t)h->maxB * h->H * h->Scap * h->hd;
-        h->kvc_part = (size_t)h->nl * h->maxB * h->H * h->Tcap * h->hd;
-        h->kvc_layer = (size_t)h->maxB * h->H * h->Tcap * h->hd;
+        h->kx_rows = h->Scap;                    // (300 rows: not a power-of-two stride; an extra row measured no gain)
+        h->kvx_part = (size_t)h->nl * h->maxB * h->H * h->kx_rows * h->hd;
+        h->kvx_layer = (size_t)h->maxB * h->H * h->kx_rows * h->hd;
+        h->kv_rows = h->Tcap | 1;
+        if (const char* e = getenv("AMT_KV_PAD")) h->kv_rows = h->Tcap + atoi(e);      // experiments: 0 = the aliased power-of-two stride
+        h->kvc_part = (size_t)h->nl * h->maxB * h->H * h->kv_rows * h->hd;
+        h->kvc_layer = (size_t)h->maxB * h->H * h->kv_rows * h->hd;
         if ((rc = dev_alloc(h, &h->KVx, 2 * h->kvx_part))) return rc;
         if ((rc = dev_alloc(h, &h->KVc, 2 * h->kvc_part))) return rc;
         if ((rc = dev_alloc(h, &h->memory, (size_t)h->maxB * h->Scap * d))) return rc;
@@ -733,7 +740,7 @@ extern "C" int32_t amt_encode(amt_handle* h, int32_t B, int32_t S, const float* 
     for (int l = 0; l < h->nl; ++l) {
         const DecLayer& D = h->dec[l];
         GemmParams g = gemm_params(h->memory, d, D.ca_w + (size_t)d * d, d, h->KVx + (size_t)l * h->kvx_layer, 0, R, 2 * d, d, D.ca_b + d);
-        g.head_split = 1; g.hs_seq = S; g.hs_seq_cap = h->Scap; g.hs_d = d; g.hs_hd = h->hd; g.hs_heads = h->H;
+        g.head_split = 1; g.hs_seq = S; g.hs_seq_cap = h->kx_rows; g.hs_d = d; g.hs_hd = h->hd; g.hs_heads = h->H;
         g.hs_part_stride = h->kvx_part;
         if ((rc = amt_launch_gemm(g, s))) return rc;
     }
@@ -775,7 +782,7 @@ extern "C" int32_t amt_prefill(amt_handle* h, int32_t B, int32_t L, const int64_
         AttnParams c{};
         c.q = h->wsQc; c.k = h->KVx + (size_t)l * h->kvx_layer; c.v = c.k + h->kvx_part; c.o = h->wsO;
         c.q_bs = (size_t)L * d; c.q_hs = h->hd; c.q_ls = d;
-        c.k_bs = c.v_bs = (size_t)h->H * h->Scap * h->hd; c.k_hs = c.v_hs = (size_t)h->Scap * h->hd; c.k_ls = c.v_ls = h->hd;
+        c.k_bs = c.v_bs = (size_t)h->H * h->kx_rows * h->hd; c.k_hs = c.v_hs = (size_t)h->kx_rows * h->hd; c.k_ls = c.v_ls = h->hd;
         c.o_bs = (size_t)L * d; c.o_hs = h->hd; c.o_ls = d;
         c.B = B; c.H = h->H; c.Lq = L; c.Lk = S; c.hd = h->hd; c.kv_group = 1;
         if ((rc = amt_launch_attn_prefill(c, s))) return rc;

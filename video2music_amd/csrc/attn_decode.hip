@@ -104,7 +104,7 @@ __device__ __forceinline__ void stream_keys(Batch<HD>& cur, Batch<HD>& nxt, cons
     }
 }
 
-constexpr int UCH = 4;           // folded prologue: the pre-LN row has at most UCH*256 floats
+constexpr int UCH_MAX = 4;       // folded prologue: the pre-LN row has at most UCH*256 floats (UCH = 2 or 4 by the model's width)
 
 // FOLD: 0 plain query, 1 folded-LayerNorm prologue, 2 the same plus the new key/value of this position, 3 = 1 plus the rotary
 // embedding of the query (the lockstep V1/V2 step: q = rope(LayerNorm(u) . Wq^T + b) * scale)
@@ -114,7 +114,7 @@ constexpr int UCH = 4;           // folded prologue: the pre-LN row has at most 
 #define ASTAMP(i) do { } while (0)
 #endif
 
-template <int HD, bool RPR, bool NT, int FOLD>
+template <int HD, bool RPR, bool NT, int FOLD, int UCH>
 __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnDecodeParams p) {
 #ifdef AMT_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -158,8 +158,11 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnDecodeParams p
         float4 uv[UCH];
 #pragma unroll
         for (int i = 0; i < UCH; ++i) {
-            const int k = (i * 64 + lane) * 4;
-            uv[i] = k < d ? ld4(ub + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            // unguarded (columns past d re-read the row's last float4 and are left out of the sums below): `k < d ? load : 0`
+            // makes the compiler write the zero after the load and therefore wait for EVERY load in flight (vmcnt(0)) -- here the
+            // whole first K/V batch -- before it issues the rest of the prologue's loads: two serial round trips
+            const int k = min((i * 64 + lane) * 4, d - 4);
+            uv[i] = ld4(ub + k);
         }
         const float* raw = p.q + (size_t)b * p.ldq + col;
         const float4 rq = ld4(raw), gq = ld4(p.fold_g + col), cq = ld4(p.fold_c + col);
@@ -174,10 +177,12 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnDecodeParams p
         // the first batch's Er rows need only the position: issued behind the prologue's loads, they land while the
         // statistics are reduced instead of costing one more L2 round trip after the query exists
         if (RPR && FOLD == 2) load_er<HD>(b0, eb, j0, sub, c4, n_keys);
+        __builtin_amdgcn_sched_barrier(0);             // no consumer of a loaded value moves in front of the loads above
         const float inv_d = 1.0f / (float)d;
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < UCH; ++i) s += (uv[i].x + uv[i].y) + (uv[i].z + uv[i].w);
+        for (int i = 0; i < UCH; ++i)
+            if ((i * 64 + lane) * 4 < d) s += (uv[i].x + uv[i].y) + (uv[i].z + uv[i].w);
         const float mean = wave_sum(s) * inv_d;
         float qq = 0.f;
 #pragma unroll
@@ -205,14 +210,22 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnDecodeParams p
             vn4.z = (rv.z - mean * gv.z) * rstd + cv.z; vn4.w = (rv.w - mean * gv.w) * rstd + cv.w;
         }
         if (p.xn && h == 0 && wave == 0) {        // LayerNorm(u[b]): the residual of the following block
+            // all affine vectors requested at once (unguarded, clamped), then the stores: a load under `k < d` per chunk made
+            // this one wave of the clip walk UCH serial L2 round trips, and the workgroup's final barrier waits for it
+            float4 w4[UCH], b4[UCH];
+#pragma unroll
+            for (int i = 0; i < UCH; ++i) {
+                const int kc = min((i * 64 + lane) * 4, d - 4);
+                w4[i] = ld4(p.fold_lnw + kc);
+                b4[i] = ld4(p.fold_lnb + kc);
+            }
 #pragma unroll
             for (int i = 0; i < UCH; ++i) {
                 const int k = (i * 64 + lane) * 4;
                 if (k < d) {
-                    const float4 w4 = ld4(p.fold_lnw + k), b4 = ld4(p.fold_lnb + k);
                     float4 y;
-                    y.x = (uv[i].x - mean) * rstd * w4.x + b4.x; y.y = (uv[i].y - mean) * rstd * w4.y + b4.y;
-                    y.z = (uv[i].z - mean) * rstd * w4.z + b4.z; y.w = (uv[i].w - mean) * rstd * w4.w + b4.w;
+                    y.x = (uv[i].x - mean) * rstd * w4[i].x + b4[i].x; y.y = (uv[i].y - mean) * rstd * w4[i].y + b4[i].y;
+                    y.z = (uv[i].z - mean) * rstd * w4[i].z + b4[i].z; y.w = (uv[i].w - mean) * rstd * w4[i].w + b4[i].w;
                     st4(p.xn + (size_t)b * d + k, y);
                 }
             }
@@ -311,8 +324,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnDecodeParams p
 #endif
 }
 
-template <int HD, int FOLD>
-void launch_decode(const AttnDecodeParams& p, hipStream_t stream) {
+template <int HD, int FOLD, int UCH>
+void launch_decode_u(const AttnDecodeParams& p, hipStream_t stream) {
     dim3 grid(p.H, p.B);
     // K/V are streamed once per launch and exceed the 256 MiB Infinity Cache per step: non-temporal loads keep
     // the step's re-used bytes (weights, activations) resident instead (measured +8 % tokens/s at
@@ -320,12 +333,19 @@ void launch_decode(const AttnDecodeParams& p, hipStream_t stream) {
     static int nt_mask = -1;
     if (nt_mask < 0) { const char* e = getenv("AMT_NT"); nt_mask = e ? atoi(e) : 3; }
     if (p.Er) {
-        if (nt_mask & 1) hipLaunchKernelGGL((attn_decode_kernel<HD, true, true, FOLD>), grid, dim3(NW * 64), 0, stream, p);
-        else hipLaunchKernelGGL((attn_decode_kernel<HD, true, false, FOLD>), grid, dim3(NW * 64), 0, stream, p);
+        if (nt_mask & 1) hipLaunchKernelGGL((attn_decode_kernel<HD, true, true, FOLD, UCH>), grid, dim3(NW * 64), 0, stream, p);
+        else hipLaunchKernelGGL((attn_decode_kernel<HD, true, false, FOLD, UCH>), grid, dim3(NW * 64), 0, stream, p);
     } else {
-        if (nt_mask & 2) hipLaunchKernelGGL((attn_decode_kernel<HD, false, true, FOLD>), grid, dim3(NW * 64), 0, stream, p);
-        else hipLaunchKernelGGL((attn_decode_kernel<HD, false, false, FOLD>), grid, dim3(NW * 64), 0, stream, p);
+        if (nt_mask & 2) hipLaunchKernelGGL((attn_decode_kernel<HD, false, true, FOLD, UCH>), grid, dim3(NW * 64), 0, stream, p);
+        else hipLaunchKernelGGL((attn_decode_kernel<HD, false, false, FOLD, UCH>), grid, dim3(NW * 64), 0, stream, p);
     }
+}
+
+// the prologue keeps the pre-LayerNorm row in UCH float4 per lane: two for d_model <= 512 (config 2), four up to 1024
+template <int HD, int FOLD>
+void launch_decode(const AttnDecodeParams& p, hipStream_t stream) {
+    if (FOLD == 0 || p.d <= 512) launch_decode_u<HD, FOLD, 2>(p, stream);
+    else launch_decode_u<HD, FOLD, 4>(p, stream);
 }
 
 }  // namespace
@@ -333,9 +353,10 @@ void launch_decode(const AttnDecodeParams& p, hipStream_t stream) {
 int32_t amt_launch_attn_decode(const AttnDecodeParams& p, hipStream_t stream) {
     AMT_CHECK_ARG(p.B > 0 && p.H > 0 && p.cap > 0, "attn_decode: bad shape B=%d H=%d cap=%d", p.B, p.H, p.cap);
     AMT_CHECK_ARG(p.pos != nullptr || (p.n_keys > 0 && p.n_keys <= p.cap), "attn_decode: n_keys=%d outside (0,%d]", p.n_keys, p.cap);
-    AMT_CHECK_ARG(p.Er == nullptr || p.er_len >= p.cap, "attn_decode: er_len=%d smaller than the key capacity %d", p.er_len, p.cap);
+    // (cap is the row count per (clip, head) in memory and may carry one padding row that keeps the heads off a power-of-two stride)
+    AMT_CHECK_ARG(p.Er == nullptr || p.er_len + 1 >= p.cap, "attn_decode: er_len=%d smaller than the key capacity %d", p.er_len, p.cap);
     if (p.fold_u) {
-        AMT_CHECK_ARG(p.fold_g && p.fold_c && p.d == p.H * p.hd && p.d % 4 == 0 && p.d <= UCH * 256 && p.ldq >= p.d && p.ldq % 4 == 0,
+        AMT_CHECK_ARG(p.fold_g && p.fold_c && p.d == p.H * p.hd && p.d % 4 == 0 && p.d <= UCH_MAX * 256 && p.ldq >= p.d && p.ldq % 4 == 0,
                       "attn_decode: bad folded prologue (d=%d ldq=%d)", p.d, p.ldq);
         AMT_CHECK_ARG(!p.xn || (p.fold_lnw && p.fold_lnb), "attn_decode: xn needs the LayerNorm affine");
         AMT_CHECK_ARG(!p.new_kv || (p.pos && p.k_new && p.v_new && p.ldq >= 3 * p.d), "attn_decode: new_kv needs pos, the cache and 3d raw columns");

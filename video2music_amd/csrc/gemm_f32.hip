@@ -58,7 +58,8 @@ __device__ __forceinline__ void store_out(const GemmParams& p, int row, int col,
 template <int TM, int TN, bool GATHER = false, int PF = 2>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     constexpr int BM = 64 * TM, BN = 64 * TN, BMAX = BM > BN ? BM : BN;
-    __shared__ __attribute__((aligned(16))) float lds[2][2][BMAX * LDS_LD];   // [buf][A|W][row][k]
+    __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * LDS_LD];   // [buf][A rows | W rows][k]
+    constexpr int WOFF = BM * LDS_LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 
@@ -104,9 +105,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     };
     auto lstore = [&](int buf, int st) {
 #pragma unroll
-        for (int i = 0; i < 2 * TM; ++i) st4(&lds[buf][0][(srow + i * 32) * LDS_LD + scol], ra[st][i]);
+        for (int i = 0; i < 2 * TM; ++i) st4(&lds[buf][(srow + i * 32) * LDS_LD + scol], ra[st][i]);
 #pragma unroll
-        for (int i = 0; i < 2 * TN; ++i) st4(&lds[buf][1][(srow + i * 32) * LDS_LD + scol], rw[st][i]);
+        for (int i = 0; i < 2 * TN; ++i) st4(&lds[buf][WOFF + (srow + i * 32) * LDS_LD + scol], rw[st][i]);
     };
 
     f32x16 acc[TM][TN];
@@ -129,8 +130,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         const int cur = kt & 1;
         gload(min(kt + PF, nk - 1) * BK, PF == 2 ? ST ^ 1 : 0);          // unconditional (the last two trips re-read the last k-tile): a guarded
                                                          // load hides the number of loads in flight and every wait becomes vmcnt(0)
-        const float* la = &lds[cur][0][(wr * 32 * TM + fr) * LDS_LD + fh * 4];
-        const float* lw = &lds[cur][1][(wc * 32 * TN + fr) * LDS_LD + fh * 4];
+        const float* la = &lds[cur][(wr * 32 * TM + fr) * LDS_LD + fh * 4];
+        const float* lw = &lds[cur][WOFF + (wc * 32 * TN + fr) * LDS_LD + fh * 4];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 8) {
             float4 af[TM], bf[TN];
@@ -179,8 +180,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     // transpose the tile through LDS (the operand buffers are free now) so that every lane owns 4 consecutive
     // columns: bias / residual / gate loads and the output stores become 16-byte and row-contiguous
     constexpr int CLD = BN + 4;
-    static_assert(BM * CLD <= 2 * 2 * BMAX * LDS_LD, "output tile does not fit the operand buffers");
-    float* ct = &lds[0][0][0];
+    static_assert(BM * CLD <= 2 * (BM + BN) * LDS_LD, "output tile does not fit the operand buffers");
+    float* ct = &lds[0][0];
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < TM; ++i)
