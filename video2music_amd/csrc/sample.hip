@@ -302,10 +302,16 @@ __global__ __launch_bounds__(256) void sample_fold_kernel(SampleParams p) {
     if (wave == 0) {
         const float inv_d = 1.0f / (float)d;
         float4 v[KCH];
+        // unguarded, clamped loads (columns past d re-read the last float4 and stay out of the sums): a load under a branch, or a
+        // `cond ? load : 0`, makes the compiler drain the loads in flight; the LayerNorm affine used to be fetched chunk by chunk
+        // inside the pass loop, two serial L2 round trips
+        float4 lw[KCH], lb[KCH];
 #pragma unroll
         for (int c = 0; c < KCH; ++c) {
-            const int i = (c * 64 + lane) * 4;
-            v[c] = (i < d) ? ld4(p.u + (size_t)b * p.ldu + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int i = min((c * 64 + lane) * 4, d - 4);
+            v[c] = ld4(p.u + (size_t)b * p.ldu + i);
+            lw[c] = ld4(p.ln_w + i);
+            lb[c] = ld4(p.ln_b + i);
         }
         float raw[3], a1[3], a2[3], a3[3], a4[3];
 #pragma unroll
@@ -319,7 +325,8 @@ __global__ __launch_bounds__(256) void sample_fold_kernel(SampleParams p) {
         for (int pass = 0; pass < 2; ++pass) {
             float s = 0.f;
 #pragma unroll
-            for (int c = 0; c < KCH; ++c) s += v[c].x + v[c].y + v[c].z + v[c].w;
+            for (int c = 0; c < KCH; ++c)
+                if ((c * 64 + lane) * 4 < d) s += v[c].x + v[c].y + v[c].z + v[c].w;
             const float mean = wave_sum(s) * inv_d;
             float q = 0.f;
 #pragma unroll
@@ -337,7 +344,7 @@ __global__ __launch_bounds__(256) void sample_fold_kernel(SampleParams p) {
                 for (int c = 0; c < KCH; ++c) {
                     const int i = (c * 64 + lane) * 4;
                     if (i < d) {
-                        const float4 g = ld4(p.ln_w + i), h = ld4(p.ln_b + i);
+                        const float4 g = lw[c], h = lb[c];
                         v[c].x = (v[c].x - mean) * rstd * g.x + h.x; v[c].y = (v[c].y - mean) * rstd * g.y + h.y;
                         v[c].z = (v[c].z - mean) * rstd * g.z + h.z; v[c].w = (v[c].w - mean) * rstd * g.w + h.w;
                     }
