@@ -115,7 +115,7 @@ constexpr int UCH_MAX = 4;       // folded prologue: the pre-LN row has at most 
 #endif
 
 template <int HD, bool RPR, bool NT, int FOLD, int UCH>
-__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnDecodeParams p) {
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_decode_kernel(AttnDecodeParams p) {
 #ifdef AMT_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
