@@ -115,7 +115,11 @@ constexpr int UCH_MAX = 4;       // folded prologue: the pre-LN row has at most 
 #endif
 
 template <int HD, bool RPR, bool NT, int FOLD, int UCH>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_decode_kernel(AttnDecodeParams p) {
+// hd = 64 at d_model <= 512 (the benchmark's shape) is held at 128 VGPRs = two workgroups per CU: it fits without spilling and a
+// launch of more than 256 workgroups (more than 32 clips per chain) then runs in one round (+6-7 % tokens/s at 64-256 clips); the
+// other shapes keep the compiler's own choice (the same bound makes the hd = 16 / 32 relative-position variants spill)
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((HD == 64 && UCH == 2) ? 4 : 1, (HD == 64 && UCH == 2) ? 4 : 8)))
+void attn_decode_kernel(AttnDecodeParams p) {
 #ifdef AMT_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
