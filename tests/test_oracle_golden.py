@@ -337,3 +337,23 @@ def test_shared_moe_temperature_scheduler(golden):
         y = O.moe_forward(torch.from_numpy(g["moe_t_x"]), sd, 8, k=2, shared=True, temperature=ts[c])
         assert np.abs(y.numpy() - g[f"moe_t_y{c}"]).max() < TOL
     assert np.abs(g["moe_t_y0"] - g["moe_t_y1"]).max() > 1e-4
+
+
+def test_v2_bench_width_fixture(golden):
+    """oracle/make_goldens_v2_wide.py: the reference V2 class at d_model 512 / 8 heads / d_ff 1024 / 6 layers."""
+    from tests.helpers import CFG_V2, synthetic_sd_v2
+    g = golden("g_v2_wide.npz")
+    assert g["g2_margins"].min() >= 1e-2 and len(set(g["g2"].flatten().tolist())) >= 8
+    sd = synthetic_sd_v2(dict(CFG_V2, n_layers=6, num_heads=8, d_model=512, dim_feedforward=1024), seed=int(g["seed"]), recipe="feedback")
+    f = feats_t(synthetic.synthetic_features(2, seed=4321), slice(0, 1), key=g["key"])
+    lg = O.forward_v2(sd, 8, torch.from_numpy(g["fwd_root"]), torch.from_numpy(g["fwd_attr"]), f["semantic"], f["key"], f["scene_offset"],
+                      f["motion"], f["emotion"])
+    assert np.abs(lg.numpy() - g["fwd_logits"]).max() < 1e-3           # logits of magnitude ~130: 1e-5 relative
+    # the generated ids are the arg-max of the row before them (feedback-greedy, N suppressed, no triple repeats)
+    ids = g["g2"][0]
+    for cur in range(1, len(ids)):
+        p = torch.softmax(lg[0, cur - 1], -1)[:157].clone()
+        p[0] = 0.0
+        if cur >= 2 and ids[cur - 1] == ids[cur - 2]:
+            p[ids[cur - 1]] = 0.0
+        assert int(p.argmax()) == int(ids[cur]), cur

@@ -246,3 +246,37 @@ def test_v2_options_vs_reference_golden(golden, tag, version):
         m.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=0).items()})
         return m.cuda()
     check_family_options(golden, tag, mid(), mid)
+
+
+def test_v2_at_bench_width_vs_reference_golden(golden):
+    """The reference VideoMusicTransformer_V2('2.2') itself at d_model 512 / 8 heads / d_ff 1024 / 6 layers (tests/golden/
+    g_v2_wide.npz, oracle/make_goldens_v2_wide.py): forward logits, G1 and G2 ids -- per clip, and with the clip as row 5 of a
+    32-clip lockstep batch, where the step takes its wide-product kernels and the folded out-projection + query projection."""
+    g = golden("g_v2_wide.npz")
+    cfg = dict(CFG_V2, version_name="2.2", n_layers=6, num_heads=8, d_model=512, dim_feedforward=1024)
+    m = VideoMusicTransformer_V2(**cfg).eval()
+    shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=int(g["seed"]), recipe="feedback").items()})
+    m = m.cuda()
+    assert g["g2_margins"].min() >= 1e-2 and len(set(g["g2"].flatten().tolist())) >= 8
+    feats = synthetic.synthetic_features(2, seed=4321)
+    f = {k: v.cuda() for k, v in feats_t(feats, slice(0, 1), key=g["key"]).items()}
+    T = g["g2"].shape[1]
+    pr = tuple(torch.tensor([int(v)]) for v in g["primer"])
+    with torch.no_grad():
+        root, attr = torch.from_numpy(g["fwd_root"]), torch.from_numpy(g["fwd_attr"])
+        y = m(root, root, attr, f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"])
+        assert np.abs(y.cpu().numpy() - g["fwd_logits"]).max() < 1e-3           # logits of magnitude ~130
+        kw = dict(feature_semantic_list=f["semantic"], feature_key=f["key"][0], feature_scene_offset=f["scene_offset"], feature_motion=f["motion"],
+                  feature_emotion=f["emotion"], primer=pr[0], primer_root=pr[1], primer_attr=pr[2], target_seq_length=T)
+        assert np.array_equal(m.generate(beam=0, sampler="argmax", **kw).cpu().numpy(), g["g2"])
+        assert np.array_equal(m.generate(beam=1, **kw).cpu().numpy(), g["g1"])
+        big = synthetic.synthetic_features(32, seed=99)
+        for k in big:
+            big[k][5] = feats[k][0]
+        key32 = big["key"].copy()
+        key32[5] = g["key"][0]
+        fb = {k: v.cuda() for k, v in feats_t(big, key=key32).items()}
+        toks = m.generate_batch(fb["semantic"], fb["key"], fb["scene_offset"], fb["motion"], fb["emotion"], *pr, target_seq_length=T,
+                                beam=0, sampler="argmax")
+        assert np.array_equal(toks[5].cpu().numpy(), g["g2"][0])
