@@ -137,15 +137,21 @@ def test_v1_options_vs_reference_golden(golden):
     check_family_options(golden, "v11", build("1.1"), lambda **over: build("1.1", **over))
 
 
-def test_lockstep_at_bench_width_equals_per_clip_generate():
+@pytest.mark.parametrize("family,version", [("v2", "2.2"), ("v1", "1.0"), ("v1", "1.1"), ("v1", "1.3.3")])
+def test_lockstep_at_bench_width_equals_per_clip_generate(family, version):
     """The lockstep step at the width the V2 bench runs (d_model 512, d_ff 1024, 32 clips): there its wide products take the
-    several-tiles-per-workgroup kernels (stacked gate|up matrix, grouped down projections) and the self-attention out-projection
-    rides with the folded cross-attention query projection; clip by clip the ids must still equal `generate` on that clip alone
-    (one-call step with device-routed experts, separate launches)."""
+    several-tiles-per-workgroup kernels (stacked gate|up matrix, grouped down projections -- with GLU experts and with the V1
+    family's Linear -> SiLU -> Linear experts, with and without a shared expert) and the self-attention out-projection rides with
+    the folded cross-attention query projection; clip by clip the ids must still equal `generate` on that clip alone (one-call
+    step with device-routed experts, separate launches)."""
     from tests.helpers import CFG_V2
     from video2music_amd.model.video_music_transformer import VideoMusicTransformer_V2
     B, T = 32, 20
-    m = VideoMusicTransformer_V2(**dict(CFG_V2, version_name="2.2", n_layers=4, num_heads=8, d_model=512, dim_feedforward=1024)).eval()
+    wide = dict(n_layers=4, num_heads=8, d_model=512, dim_feedforward=1024)
+    if family == "v2":
+        m = VideoMusicTransformer_V2(**dict(CFG_V2, version_name=version, **wide)).eval()
+    else:
+        m = VideoMusicTransformer_V1(version_name=version, **dict(CFG, **wide)).eval()
     shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=0, recipe="feedback").items()})
     m = m.cuda()
@@ -153,7 +159,7 @@ def test_lockstep_at_bench_width_equals_per_clip_generate():
     pr = (torch.tensor([1]), torch.tensor([1]), torch.tensor([0]))
     with torch.no_grad():
         got = m.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], *pr, target_seq_length=T, beam=0, sampler="argmax")
-        assert len(set(got[:, 1:].flatten().tolist())) >= 8
+        assert len(set(got[:, 1:].flatten().tolist())) >= 4
         for c in (0, 13, 31):
             one = m.generate(f["semantic"][c:c + 1], f["key"][c], f["scene_offset"][c:c + 1], f["motion"][c:c + 1], f["emotion"][c:c + 1],
                              *pr, target_seq_length=T, beam=0, sampler="argmax", decision="host")
