@@ -194,22 +194,26 @@ def prefill_roofline(B, L, S, H, hd, device, reps=20):
     def run():
         _lib.call("amt_cross_attn_fwd", _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), B, H, L, S, hd, 0, _lib.stream_ptr())
 
-    for _ in range(3):
-        run()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
+    # this leg runs right behind the latency-bound decode legs: the first launches of a dense kernel see the clocks of an almost
+    # idle chip, so warm up with as many launches as are timed and keep the better of two timed rounds
     for _ in range(reps):
         run()
-    b.record()
-    torch.cuda.synchronize()
-    us = 1e3 * a.elapsed_time(b) / reps
+    us = float("inf")
+    for _ in range(2):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            run()
+        b.record()
+        torch.cuda.synchronize()
+        us = min(us, 1e3 * a.elapsed_time(b) / reps)
     flop = 4.0 * B * L * S * d
     return {"bound": "mfma", "kernel": "attn_prefill_kernel<64, false> (cross-attention QK^T + PV of the teacher-forced forward)",
             "shape": f"B={B} L={L} S={S} H={H} hd={hd} (grid (2048,8,32)/256... one launch per decoder layer of the config-2 forward)",
             "flop_per_launch": flop, "avg_launch_us": round(us, 2), "achieved": round(flop / us / 1e6, 2), "peak": MFMA_F32_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(flop / us / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "dtype": "f32 in / f32 accumulate (v_mfma_f32_32x32x2_f32)",
             "measured": f"HIP events on the launch stream around {reps} back-to-back launches of the operator entry point (same kernel, "
-                        "same grid as the forward's)"}
+                        f"same grid as the forward's), after {reps} warm-up launches, better of two rounds"}
 
 
 def roofline(model, f, prim, B, T, cfg):
