@@ -142,3 +142,48 @@ def test_second_device_after_the_first():
             outs.append(m.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], pr, prr, pra,
                                          target_seq_length=40, beam=0, sampler="argmax").cpu())
     assert torch.equal(outs[0], outs[1])
+
+
+RCCL_ONE_RANK_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["AMT_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from video2music_amd import synthetic
+from video2music_amd.model.moe import GLUExpert, MoELayer, SharedMoELayer
+from tests.test_oracle_golden import moe_shapes
+
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)     # a real RCCL communicator, one member
+assert dist.get_backend() == "nccl"
+# the collectives of the data-parallel generate (video2music_amd/dist.py, bench.py) on HBM tensors
+ids = (torch.arange(32, device=dev).view(-1, 1) * 10000 + torch.arange(1024, device=dev).view(1, -1)).long()
+out = torch.empty_like(ids)
+dist.all_gather_into_tensor(out, ids)
+assert torch.equal(out, ids)
+t = torch.tensor([3.5], dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert float(t) == 3.5
+dist.barrier()
+# the expert-parallel exchange (counts + rows out + rows back: three all_to_all_single per call) with every expert local
+d, dff = 128, 256
+for shared in (False, True):
+    layer = SharedMoELayer(GLUExpert(d, dff), d) if shared else MoELayer(GLUExpert(d, dff), d)
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(moe_shapes(8, d, dff, shared), seed=5).items()}
+    layer.load_state_dict(sd, strict=False)
+    layer = layer.cuda(0).eval()
+    x = torch.from_numpy(np.random.RandomState(7).standard_normal((40, 3, d)).astype(np.float32)).cuda(0)
+    ref = layer(x).clone()
+    layer.enable_expert_parallel()
+    err = (layer(x) - ref).abs().max().item()
+    assert err < 2e-5, (shared, err)
+dist.barrier(); dist.destroy_process_group()
+print("rccl one-rank ok")
+"""
+
+
+def test_rccl_communicator_and_collectives_one_rank(tmp_path):
+    """What a one-GPU box can show of the RCCL path: backend "nccl" loads, creates a communicator bound to the device and runs the
+    path's collectives (all_gather_into_tensor, all_reduce MAX, barrier, all_to_all_single) on HBM tensors; the expert-parallel
+    MoE orchestration over it equals the local layer.  The exchange itself (two members and more) needs the tests above."""
+    run_ranks(tmp_path, RCCL_ONE_RANK_WORKER, world=1)
