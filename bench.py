@@ -216,6 +216,40 @@ def prefill_roofline(B, L, S, H, hd, device, reps=20):
                         f"same grid as the forward's), after {reps} warm-up launches, better of two rounds"}
 
 
+def forward_leg(model, f, B, T, cfg, reps=5):
+    """SURVEY.md §8(d) "also report the prefill forward separately": the teacher-forced forward of the same configuration
+    (video encode + 6 decoder layers over B x T chord positions, model/video_music_transformer.py:913-1044) — the MFMA-bound
+    side of the path; it is also what the reference's beam=1 branch (top-1 without feedback) costs in ONE call."""
+    rs = np.random.RandomState(0)
+    dev = f["semantic"].device
+    root = torch.from_numpy(rs.randint(1, 13, size=(B, T))).to(dev)
+    attr = torch.from_numpy(rs.randint(1, 14, size=(B, T))).to(dev)
+
+    def run():
+        model(root, root, attr, f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"])
+
+    with torch.no_grad():
+        for _ in range(2):
+            run()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            run()
+        b.record()
+        torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / reps
+    d, dff, nl, S, F = cfg["d_model"], cfg["dim_feedforward"], cfg["n_layers"], 300, cfg["total_vf_dim"]
+    # dense-equivalent flop of the products the forward launches (causal self-attention counted on its visible half)
+    enc = B * S * (2 * F * d + nl * (8 * d * d + 4 * d * dff + 4 * S * d))
+    dec = B * T * nl * (8 * d * d + 4 * d * d + 4 * d * dff + 4 * S * d + 2 * T * d + T * d) + B * S * nl * 4 * d * d + B * T * 2 * d * 159
+    return {"ms": round(ms, 3), "token_positions_per_s": round(B * T / ms * 1e3), "gflop": round((enc + dec) / 1e9, 1),
+            "achieved": round((enc + dec) / ms / 1e9, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round((enc + dec) / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4), "shape": f"B={B} L={T} S={S}",
+            "flop_model": "2*m*n*k of every product of the encode + decoder forward; causal self-attention (QK^T, Q.Er, PV) counted on the "
+                          "visible half: 2*L*d per position for QK^T+PV and L*d for the relative term Q.Er^T",
+            "measured": f"HIP events around {reps} forwards (encode included) after 2 warm-up calls"}
+
+
 def roofline(model, f, prim, B, T, cfg):
     """Roofline of the decode step's kernels.
 
@@ -294,6 +328,7 @@ def roofline(model, f, prim, B, T, cfg):
         "sample_event_pair": ev("sample"),
         "whole_step": whole_step(cfg, B, T, st, full),
         "prefill": prefill_roofline(B, T, 300, cfg["num_heads"], d // cfg["num_heads"], f["semantic"].device),
+        "forward": forward_leg(model, f, B, T, cfg),
     }
 
 

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libamt_hip.so")
+# AMT_LIB: an alternate build of the same library (tools/ab_build.sh: A/B kernel experiments on one box); default = the in-tree build
+LIB_PATH = os.environ.get("AMT_LIB") or os.path.join(_HERE, "lib", "libamt_hip.so")
 
 
 class AmtError(RuntimeError):
