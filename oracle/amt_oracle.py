@@ -105,10 +105,11 @@ def rpr_self_attention(x, sd, prefix, H, causal=True):
     q = q * (float(hd) ** -0.5)
     q, k, v = split_heads(q, H), split_heads(k, H), split_heads(v, H)
     s = q @ k.transpose(-1, -2)
-    Er = sd[prefix + "Er"]
-    er = Er[max(0, Er.shape[0] - L):, :]                       # _get_valid_embedding, rpr.py:426-437
-    qe = torch.einsum("bhld,md->bhlm", q, er)
-    s = s + skew(qe)
+    Er = sd.get(prefix + "Er")          # rpr=False (video_music_transformer.py:903-911): torch's stock decoder layer, no table
+    if Er is not None:
+        er = Er[max(0, Er.shape[0] - L):, :]                   # _get_valid_embedding, rpr.py:426-437
+        qe = torch.einsum("bhld,md->bhlm", q, er)
+        s = s + skew(qe)
     if causal:
         mask = torch.triu(torch.full((L, L), float("-inf"), dtype=x.dtype), diagonal=1)
         s = s + mask

@@ -357,3 +357,19 @@ def test_v2_bench_width_fixture(golden):
         if cur >= 2 and ids[cur - 1] == ids[cur - 2]:
             p[ids[cur - 1]] = 0.0
         assert int(p.argmax()) == int(ids[cur]), cur
+
+
+def test_rpr_false_forward_and_generate(golden):
+    """The oracle without relative-position tables (no `Er` rows in the state_dict) = the reference class built with rpr=False
+    (torch's stock decoder layers, model/video_music_transformer.py:956-961): forward logits, G1, G2 of g_norpr.npz."""
+    g = golden("g_norpr.npz")
+    sd = {k: v for k, v in synthetic_sd(CFG1).items() if not k.endswith(".Er")}
+    key = np.array([[0.0], [1.0], [0.0]], dtype=np.float32)
+    f = feats_t(synthetic.synthetic_features(3, seed=1234), key=key)
+    logits = O.forward(sd, 4, torch.from_numpy(g["root"]), torch.from_numpy(g["attr"]), f["semantic"], f["key"], f["scene_offset"],
+                       f["motion"], f["emotion"])
+    assert np.abs(logits.numpy() - g["logits"]).max() < TOL
+    one = {k: v[:1] for k, v in f.items()}
+    args = (sd, 4, one["semantic"], one["key"], one["scene_offset"], one["motion"], one["emotion"], torch.tensor([1]), torch.tensor([1]), torch.tensor([0]))
+    assert np.array_equal(O.generate(*args, target_seq_length=48, beam=1).numpy(), g["g1"])
+    assert np.array_equal(O.generate(*args, target_seq_length=48, beam=0).numpy(), g["g2"])
