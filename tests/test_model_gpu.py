@@ -161,6 +161,32 @@ def test_shapes_outside_the_fold_fall_back_to_the_plain_chain():
     assert torch.equal(out.cpu(), ref)
 
 
+@pytest.mark.parametrize("d,H,ff", [(256, 4, 64), (128, 8, 64)])
+def test_plain_chain_with_a_feed_forward_narrower_than_the_model(monkeypatch, d, H, ff):
+    """The 49-launch chain (AMT_DECODE_CHAIN=plain) publishes LayerNorm(u2) from the prologue of the FFN-up product: with
+    dim_feedforward < d_model that launch has fewer column tiles than the row has 16-column blocks (the case the V2 fuzz found);
+    also head_dim 16 through both chains."""
+    cfg = dict(CFG1, d_model=d, num_heads=H, dim_feedforward=ff, n_layers=2)
+    fc = feats_t(synthetic.synthetic_features(2, seed=d + ff))
+    f = cu(fc)
+    pr, prr, pra = (torch.tensor([v]) for v in C.primer_from_name("C"))
+    outs = []
+    for chain in ("plain", "folded"):
+        if chain == "plain":
+            monkeypatch.setenv("AMT_DECODE_CHAIN", "plain")
+        else:
+            monkeypatch.delenv("AMT_DECODE_CHAIN", raising=False)
+        m, sd = build(cfg, seed=d)
+        outs.append(m.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], pr, prr, pra,
+                                     target_seq_length=18, beam=0, sampler="argmax").cpu())
+        del m
+    for b in range(2):
+        one = {k: v[b:b + 1] for k, v in fc.items()}
+        ref = O.generate(sd, H, one["semantic"], one["key"], one["scene_offset"], one["motion"], one["emotion"], pr, prr, pra,
+                         target_seq_length=18, beam=0)
+        assert torch.equal(outs[0][b:b + 1], ref) and torch.equal(outs[1][b:b + 1], ref)
+
+
 @pytest.mark.parametrize("d,H,ff", [(256, 2, 512), (256, 8, 256), (192, 3, 320)])
 def test_other_head_sizes_through_the_folded_chain(d, H, ff):
     """head_dim 128 / 32 / 64 with d_model not a power of two: greedy ids of the folded decode chain equal the oracle's and

@@ -55,6 +55,21 @@ def test_gqa_config4_vs_oracle():
     assert (both[:, :1] - alone).abs().max().item() > 1e-2
 
 
+def test_gqa_head_dim_16_vs_oracle():
+    """MultiheadGQA(128, 8, 2): head_dim 16 (the attention's O^T tile is padded to 32 rows of d), causal and not, B = 1 and 3."""
+    shapes = [("q_proj.weight", (128, 128)), ("q_proj.bias", (128,)), ("k_proj.weight", (32, 128)), ("k_proj.bias", (32,)),
+              ("v_proj.weight", (32, 128)), ("v_proj.bias", (32,)), ("norm.weight", (128,)), ("norm.bias", (128,)),
+              ("out_proj.weight", (128, 128)), ("out_proj.bias", (128,))]
+    m, sd = load(MultiheadGQA(128, 8, 2), shapes, 6)
+    rs = np.random.RandomState(1)
+    for L, B, causal in ((300, 1, True), (70, 3, False), (33, 3, True)):
+        x = torch.from_numpy(rs.standard_normal((L, B, 128)).astype(np.float32))
+        ref = O.gqa_forward(x, x, x, sd, 8, 2, is_causal=causal)
+        y, _ = m(x.cuda(), x.cuda(), x.cuda(), is_causal=causal)
+        err = (y.cpu() - ref).abs().max().item()
+        assert err < TOL, (L, B, causal, err)
+
+
 @pytest.mark.parametrize("name", ["moe", "shared"])
 def test_moe_vs_reference_golden(golden, name):
     g = golden("g_moe.npz")

@@ -85,7 +85,8 @@ def ref_rpr_attn(q, k, v, Er, H):
 
 @pytest.mark.parametrize("B,H,L,hd,er_len", [(1, 4, 1, 32, 300), (2, 4, 12, 32, 300), (3, 4, 64, 32, 300), (2, 8, 129, 64, 200),
                                             (1, 8, 300, 64, 300), (2, 2, 257, 64, 1024), (1, 2, 70, 128, 128),
-                                            (1, 8, 1024, 64, 1024)])       # config 2's full length: L = er_len = 1024
+                                            (1, 8, 1024, 64, 1024),        # config 2's full length: L = er_len = 1024
+                                            (2, 8, 1, 16, 64), (2, 8, 45, 16, 64), (1, 3, 300, 16, 300)])   # head_dim 16 (d_model 128 with 8 heads)
 def test_rpr_attention_prefill(B, H, L, hd, er_len):
     rs = np.random.RandomState(L)
     E = H * hd
@@ -99,7 +100,8 @@ def test_rpr_attention_prefill(B, H, L, hd, er_len):
 
 
 @pytest.mark.parametrize("B,H,L,hd,er_len", [(1, 4, 1, 32, 300), (2, 4, 12, 32, 300), (2, 4, 33, 32, 300), (2, 8, 129, 64, 200),
-                                            (1, 8, 300, 64, 300), (1, 2, 257, 64, 1024), (1, 2, 70, 128, 128), (1, 8, 1024, 64, 1024)])
+                                            (1, 8, 300, 64, 300), (1, 2, 257, 64, 1024), (1, 2, 70, 128, 128), (1, 8, 1024, 64, 1024),
+                                            (2, 8, 45, 16, 64)])
 def test_rpr_attention_prefill_without_causal_mask(B, H, L, hd, er_len):
     """forward(mask=False) of the reference (model/video_music_transformer.py:978-982): all keys visible, and `_skew`
     (model/rpr.py:439-455, verbatim in the oracle) leaves the relative term zero above the diagonal."""
@@ -117,7 +119,7 @@ def test_rpr_attention_prefill_without_causal_mask(B, H, L, hd, er_len):
 
 
 @pytest.mark.parametrize("B,H,Lq,Lk,hd,causal", [(2, 4, 5, 300, 32, 0), (1, 8, 300, 300, 64, 0), (2, 8, 130, 77, 64, 0),
-                                                (2, 8, 64, 64, 64, 1), (1, 2, 33, 100, 128, 0)])
+                                                (2, 8, 64, 64, 64, 1), (1, 2, 33, 100, 128, 0), (2, 8, 40, 300, 16, 0), (1, 8, 300, 300, 16, 1)])
 def test_cross_attention_prefill(B, H, Lq, Lk, hd, causal):
     rs = np.random.RandomState(Lq * 7 + Lk)
     E = H * hd
@@ -150,7 +152,7 @@ def test_softmax_rescale_branch_forced():
 
 @pytest.mark.parametrize("B,H,hd,cap,pos,rpr", [(1, 4, 32, 300, 0, True), (3, 4, 32, 300, 17, True), (32, 8, 64, 1024, 1023, True),
                                                (5, 8, 64, 1024, 500, True), (32, 8, 64, 300, 299, False), (2, 2, 128, 64, 63, False),
-                                               (2, 8, 16, 64, 40, False)])
+                                               (2, 8, 16, 64, 40, False), (3, 8, 16, 64, 63, True)])
 def test_attention_decode(B, H, hd, cap, pos, rpr):
     rs = np.random.RandomState(pos + B)
     q = rnd(rs, B, H * hd, scale=0.5)

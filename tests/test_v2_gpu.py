@@ -280,3 +280,35 @@ def test_v2_at_bench_width_vs_reference_golden(golden):
         toks = m.generate_batch(fb["semantic"], fb["key"], fb["scene_offset"], fb["motion"], fb["emotion"], *pr, target_seq_length=T,
                                 beam=0, sampler="argmax")
         assert np.array_equal(toks[5].cpu().numpy(), g["g2"][0])
+
+
+@pytest.mark.parametrize("d,H,ff,nl", [(256, 4, 64, 4), (512, 4, 192, 3)])
+def test_v2_feed_forward_narrower_than_half_the_model_width(d, H, ff, nl):
+    """2 * dim_feedforward < d_model: the stacked gate | up product of a GLU layer then has fewer column tiles than its LayerNorm
+    prologue has 16-column blocks to publish as the block's residual (found by tools/fuzz_parity.py v2: columns past 2 * d_ff of the
+    residual were never written).  Lockstep generate_batch and the one-clip generate against the oracle, clip by clip."""
+    cfg = dict(CFG_V2, version_name="2.2", n_layers=nl, num_heads=H, d_model=d, dim_feedforward=ff)
+    m = VideoMusicTransformer_V2(**cfg).eval()
+    shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=d + ff, recipe="feedback").items()}
+    m.load_state_dict(sd)
+    m = m.cuda()
+    fc = feats_t(synthetic.synthetic_features(3, seed=ff))
+    f = {k: v.cuda() for k, v in fc.items()}
+    pr = (torch.tensor([1]), torch.tensor([1]), torch.tensor([0]))
+    T = 10
+    with torch.no_grad():
+        toks = m.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], *pr, target_seq_length=T,
+                                beam=0, sampler="argmax").cpu()
+        one = m.generate(feature_semantic_list=f["semantic"][:1], feature_key=f["key"][0], feature_scene_offset=f["scene_offset"][:1],
+                         feature_motion=f["motion"][:1], feature_emotion=f["emotion"][:1], primer=pr[0], primer_root=pr[1], primer_attr=pr[2],
+                         target_seq_length=T, beam=0, sampler="argmax").cpu()
+    for b in range(3):
+        c = {k: v[b:b + 1] for k, v in fc.items()}
+        margins = []
+        ref = O.generate(sd, H, c["semantic"], c["key"], c["scene_offset"], c["motion"], c["emotion"], *pr, target_seq_length=T, beam=0,
+                         forward_fn=O.forward_v2, margins=margins)
+        assert min(margins) > 1e-3, margins
+        assert torch.equal(toks[b:b + 1], ref), (b, toks[b], ref)
+        if b == 0:
+            assert torch.equal(one, ref)

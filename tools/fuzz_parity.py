@@ -5,7 +5,7 @@ Draws model shapes, batch sizes, clip lengths, primer lengths and target lengths
   * the feedback-greedy ids (beam=0, argmax = oracle G2) and the top-1 ids (beam=1 = oracle G1) of every clip with oracle.generate;
     an id mismatch is only accepted as a near-tie when the oracle's own top-1 / top-2 margin at the first differing position is below 1e-4,
   * the decode-path logits with the forward's on the generated sequence (<= 2e-4).
-Usage: python tools/fuzz_parity.py [n_cases] [seed]      -> one JSON line per case, a summary at the end, exit 1 on any failure.
+Usage: python tools/fuzz_parity.py [n_cases] [seed] [v2]      -> one JSON line per case (third argument v2: the V2 '2.2' family), a summary at the end, exit 1 on any failure.
 """
 import json
 import os
@@ -117,9 +117,75 @@ def run_case(i, rs):
     return info
 
 
+def run_case_v2(i, rs):
+    """The same for VideoMusicTransformer_V2 '2.2' (the reference's default family): forward logits against
+    oracle.forward_v2, the lockstep generate_batch (decision on the device) against oracle.generate(forward_fn=forward_v2) clip by clip."""
+    from video2music_amd.model.video_music_transformer import VideoMusicTransformer_V2
+    hd = int(rs.choice([32, 64, 128]))
+    H = int(rs.choice([1, 2, 4, 8]))
+    while H * hd > 512:
+        H //= 2
+    d = H * hd
+    ff = int(rs.choice([d, 2 * d, 192, 320]))
+    cfg = dict(version_name="2.2", n_layers=int(rs.choice([3, 4, 6])), num_heads=H, d_model=d, dim_feedforward=ff,
+               max_sequence_chord=int(rs.choice([40, 300])), total_vf_dim=synthetic.total_vf_dim(1))
+    B, S = int(rs.choice([1, 2, 3, 5])), int(rs.choice([300, 300, 120, 17]))
+    T = int(rs.randint(2, 25))
+    P = int(rs.randint(1, min(3, T) + 1))
+    temperature = float(rs.choice([1.0, 1.0, 0.7]))
+    recipe = str(rs.choice(["default", "feedback"]))
+    info = dict(case=i, family="V2", cfg={k: v for k, v in cfg.items() if k != "total_vf_dim"}, B=B, S=S, T=T, P=P, temperature=temperature, recipe=recipe)
+    m = VideoMusicTransformer_V2(**cfg).eval()
+    shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=300 + i, recipe=recipe).items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    m = m.cuda()
+    fc = feats_t(synthetic.synthetic_features(B, seed=700 + i))
+    fc = {k: (v[:, :S].contiguous() if v.dim() > 1 and v.shape[1] == 300 else v) for k, v in fc.items()}
+    f = {k: v.cuda() for k, v in fc.items()}
+    prim = torch.tensor([C.primer_from_name(n) for n in ["C", "A:min", "D:min"][:P]])
+    fails = []
+    L = int(rs.randint(1, T + 1))
+    root = torch.from_numpy(rs.randint(0, 13, size=(B, L)))
+    attr = torch.from_numpy(rs.randint(0, 14, size=(B, L)))
+    with torch.no_grad():
+        ref = O.forward_v2(sd, H, root, attr, fc["semantic"], fc["key"], fc["scene_offset"], fc["motion"], fc["emotion"])
+        got = m(root, root, attr, f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"]).cpu()
+    info["fwd_err"] = float((got - ref).abs().max())
+    if not info["fwd_err"] < 1e-3:
+        fails.append("forward")
+    near = 0
+    for beam in (0, 1):
+        kw = dict(sampler="argmax") if beam == 0 else {}
+        with torch.no_grad():
+            out = m.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], prim[:, 0], prim[:, 1], prim[:, 2],
+                                   target_seq_length=T, beam=beam, temperature=temperature, **kw).cpu()
+        for b in range(B):
+            one = {k: v[b:b + 1] for k, v in fc.items()}
+            margins = []
+            ref_ids = O.generate(sd, H, one["semantic"], one["key"], one["scene_offset"], one["motion"], one["emotion"],
+                                 prim[:, 0], prim[:, 1], prim[:, 2], target_seq_length=T, beam=beam, forward_fn=O.forward_v2,
+                                 temperature=temperature, margins=margins if beam == 0 else None)
+            if torch.equal(out[b:b + 1], ref_ids):
+                continue
+            j = int((out[b] != ref_ids[0]).nonzero()[0])
+            margin = margins[j - P] if beam == 0 and 0 <= j - P < len(margins) else None
+            if margin is not None and margin < 1e-4:
+                near += 1
+            else:
+                fails.append(f"ids beam={beam} clip={b} pos={j} got={int(out[b, j])} want={int(ref_ids[0, j])} margin={margin}")
+    info["near_ties"] = near
+    info["fails"] = fails
+    del m
+    return info
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    if len(sys.argv) > 3 and sys.argv[3] == "v2":
+        globals()["run_case"] = run_case_v2
     rs = np.random.RandomState(seed)
     bad = 0
     t0 = time.time()
@@ -128,7 +194,7 @@ def main():
             info = run_case(i, rs)
         except Exception as e:                        # a refused shape is reported with its message, not hidden
             msg = f"{type(e).__name__}: {str(e)[:300]}"
-            refused = "amt_create failed" in msg and ("head_dim" in msg or "d_model must be" in msg)      # the library's documented shape caps
+            refused = "amt_create failed" in msg and "d_model must be" in msg      # the library's documented shape caps
             info = dict(case=i, refused=msg) if refused else dict(case=i, fails=["exception " + msg])
             info.setdefault("fails", [])
         print(json.dumps(info), flush=True)

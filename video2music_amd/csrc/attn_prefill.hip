@@ -28,9 +28,10 @@ constexpr int KT = 32;       // keys per tile
 // of the hot path keeps its exact instruction stream
 template <int HD, bool RPR, bool NOMASK = false>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
-    constexpr int LD = HD + 4;
+    constexpr int HDP = HD < 32 ? 32 : HD;   // head_dim 16: the O^T tile is still 32 rows of d; V columns 16..31 are zeros in LDS
+    constexpr int LD = HDP + 4;
     constexpr int NS = HD / 8;           // ds_read_b128 k-groups per operand row
-    constexpr int ND = HD / 32;          // 32-wide d tiles of O^T
+    constexpr int ND = HDP / 32;         // 32-wide d tiles of O^T
     constexpr int SCR = 2 * 32 * 33 > 32 * (HD + 1) ? 2 * 32 * 33 : 32 * (HD + 1);   // two 32x33 distance chunks / the O transpose
     __shared__ __attribute__((aligned(16))) float Ks[KT * LD];
     __shared__ __attribute__((aligned(16))) float Vs[KT * LD];
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
 
     // K/V tile staging: 32 rows x HD/4 float4 per tensor over 256 threads
     constexpr int F4_ROW = HD / 4, F4_TILE = KT * F4_ROW, PER_T = (F4_TILE + 255) / 256;
-    static_assert(F4_TILE % 256 == 0, "a K/V tile is a whole number of 256-thread passes");
+    static_assert(F4_TILE % 256 == 0 || F4_TILE < 256, "a K/V tile is a whole number of 256-thread passes (or part of one)");
     float4 kst[PER_T], vst[PER_T];
     auto gload = [&](int j0) {
 #pragma unroll
@@ -106,6 +107,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     float4 er_next[NS];                    // Er rows of the chunk the next tile will need (relative positions only)
     bool er_primed = false;
     // (double-buffering the tiles in LDS for one barrier per tile was measured: 587 vs 584 us at config 2 — no gain, more LDS)
+    if constexpr (HD < HDP) {              // the padding columns of the V tile: written once, never touched by lstore
+        for (int f = tid; f < KT * (HDP - HD); f += 256) Vs[(f / (HDP - HD)) * LD + HD + f % (HDP - HD)] = 0.f;
+    }
     gload(0);
     for (int kt = 0; kt < n_tiles; ++kt) {
         const int j0 = kt * KT;
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int dd = dt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            scr[li * (HD + 1) + dd] = oacc[dt][e] * inv;
+            if (HD >= 32 || dd < HD) scr[li * (HD + 1) + dd] = oacc[dt][e] * inv;
         }
     float* op = p.o + (size_t)b * p.o_bs + (size_t)h * p.o_hs;
     for (int r = 0; r < 32; ++r) {
@@ -386,8 +390,8 @@ template <int HD>
 int32_t launch_hd(const AttnParams& p, hipStream_t stream) {
     dim3 grid(cdiv(p.Lq, QB) * p.H * p.B);
     // fewer than two 128-row blocks per CU and a long key range: one 32-row block per workgroup, keys split over its waves
-    if (!p.Er && HD <= 64 && grid.x < 512 && p.Lk >= 256) {
-        hipLaunchKernelGGL((attn_prefill_splitk_kernel<(HD <= 64 ? HD : 64)>), dim3(cdiv(p.Lq, 32) * p.H * p.B), dim3(256), 0, stream, p);
+    if (!p.Er && HD >= 32 && HD <= 64 && grid.x < 512 && p.Lk >= 256) {
+        hipLaunchKernelGGL((attn_prefill_splitk_kernel<(HD >= 32 && HD <= 64 ? HD : 64)>), dim3(cdiv(p.Lq, 32) * p.H * p.B), dim3(256), 0, stream, p);
         return 0;
     }
     if (p.Er && !p.causal) hipLaunchKernelGGL((attn_prefill_kernel<HD, true, true>), grid, dim3(256), 0, stream, p);
@@ -405,10 +409,11 @@ int32_t amt_launch_attn_prefill(const AttnParams& p, hipStream_t stream) {
                   "attn_prefill: relative positions need self-attention with L=%d <= er_len=%d", p.Lq, p.er_len);
     AMT_CHECK_ARG(p.q_ls % 4 == 0 && p.k_ls % 4 == 0 && p.v_ls % 4 == 0, "attn_prefill: row strides must be multiples of 4 floats");
     switch (p.hd) {
+        case 16: launch_hd<16>(p, stream); break;
         case 32: launch_hd<32>(p, stream); break;
         case 64: launch_hd<64>(p, stream); break;
         case 128: launch_hd<128>(p, stream); break;
-        default: AMT_CHECK_ARG(false, "attn_prefill: head_dim %d not in {32,64,128}", p.hd);
+        default: AMT_CHECK_ARG(false, "attn_prefill: head_dim %d not in {16,32,64,128}", p.hd);
     }
     AMT_LAUNCH_CHECK();
     return 0;

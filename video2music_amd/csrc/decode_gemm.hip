@@ -249,10 +249,12 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
     const int t = *(p.pos ? p.pos : reinterpret_cast<const int*>(p.zero));
 
     // the normalised rows are the residual of the following block: workgroup (nt, m-block) publishes its
-    // 16 rows x columns 16nt..16nt+15
-    if (LN1 && p.xn && nt * 16 < K && tid < 256) {
+    // 16 rows x columns 16nt..16nt+15 -- and, when the product has fewer column tiles than the rows have 16-column blocks
+    // (N < K: a feed-forward narrower than half the model width), the blocks one grid width further on as well
+    if (LN1 && p.xn && tid < 256) {
         const int rr = tid >> 4, c = tid & 15;
-        if (m0 + rr < p.B) p.xn[(size_t)(m0 + rr) * K + nt * 16 + c] = xs[rr * LD + nt * 16 + c];
+        for (int cb = nt * 16; cb < K; cb += (int)gridDim.x * 16)
+            if (m0 + rr < p.B) p.xn[(size_t)(m0 + rr) * K + cb + c] = xs[rr * LD + cb + c];
     }
     // folded FFN: the LayerNorm half of the staged row is the residual of the low columns
     if (PRO == 2 && live && !high) e_res = xs[(row - m0) * LD + K1 + n];

@@ -310,7 +310,7 @@ extern "C" int64_t amt_v2_step_batch_ws_floats(int32_t E, int32_t dff, int32_t n
 namespace {
 
 // One skinny-GEMM launch of the lockstep step with the fusions of round 2 (each replaces a separate launch):
-//   ln_w / ln_b : LayerNorm of the input rows in the prologue, the normalised rows also written to xn (needs N >= K)
+//   ln_w / ln_b : LayerNorm of the input rows in the prologue, the normalised rows also written to xn
 //   rope        : rotary epilogue on the first rope_cols output columns (position from device memory)
 //   qkv         : mode-1 epilogue -- q scaled to y, k / v rows of this position into the head-major caches
 //   gate        : gated-linear-unit prologue, input row = x * silu(gate) (or silu(gate) when x == null)

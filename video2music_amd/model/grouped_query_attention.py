@@ -51,8 +51,8 @@ class MultiheadGQA(nn.Module):
         if query.device.type != "cuda":
             raise _lib.AmtError("MultiheadGQA runs on an MI355X only; video2music_amd has no CPU fallback")
         hd = self.embed_dim // self.query_heads
-        if hd not in (32, 64, 128):
-            raise NotImplementedError(f"head_dim {hd}: the gfx950 attention kernel is built for 32, 64 and 128")
+        if hd not in (16, 32, 64, 128):
+            raise NotImplementedError(f"head_dim {hd}: the gfx950 attention kernel is built for 16, 32, 64 and 128")
         L, B, E = query.shape
         S = key.shape[0]
         q, k, v = (t.to(torch.float32).contiguous() for t in (query, key, value))
