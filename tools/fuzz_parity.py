@@ -5,7 +5,7 @@ Draws model shapes, batch sizes, clip lengths, primer lengths and target lengths
   * the feedback-greedy ids (beam=0, argmax = oracle G2) and the top-1 ids (beam=1 = oracle G1) of every clip with oracle.generate;
     an id mismatch is only accepted as a near-tie when the oracle's own top-1 / top-2 margin at the first differing position is below 1e-4,
   * the decode-path logits with the forward's on the generated sequence (<= 2e-4).
-Usage: python tools/fuzz_parity.py [n_cases] [seed] [v2]      -> one JSON line per case (third argument v2: the V2 '2.2' family), a summary at the end, exit 1 on any failure.
+Usage: python tools/fuzz_parity.py [n_cases] [seed] [v2]      -> one JSON line per case (third argument v2: the V2 '2.2' family against the oracle; families: V1 / V2 / V3 cached decode against their own re-forward; modules: MultiheadGQA / MoELayer / SharedMoELayer against the oracle; reg: VideoRegression against oracle/reg_oracle.py), a summary at the end, exit 1 on any failure.
 """
 import json
 import os
@@ -181,11 +181,158 @@ def run_case_v2(i, rs):
     return info
 
 
+def run_case_families(i, rs):
+    """V1 ('1.0' ... '1.3.4', rms_norm on / off), V2 ('2.0', '2.1', '2.2') and V3 ('3.0' - '3.2') at random shapes.  The oracle holds
+    only V2 '2.2'; the other families are pinned by goldens of the reference classes at their default shapes (tests/golden/g_v1, g_v2_variants,
+    g_v3), so here the cached / lockstep decode (skinny-GEMM step kernels) is compared with the per-step re-forward of the prefix on the
+    operator kernels (use_cache=False: the reference's loop, the path those goldens pin) clip by clip."""
+    from video2music_amd.model.video_music_transformer import VideoMusicTransformer_V1, VideoMusicTransformer_V2, VideoMusicTransformer_V3
+    version = str(rs.choice(["1.0", "1.1", "1.2", "1.3", "1.3.3", "1.3.4", "2.0", "2.1", "2.2", "3.0", "3.1", "3.2"]))
+    cls = {"1": VideoMusicTransformer_V1, "2": VideoMusicTransformer_V2, "3": VideoMusicTransformer_V3}[version[0]]
+    hd = int(rs.choice([16, 32, 64, 128]))
+    H = int(rs.choice([1, 2, 4, 8]))
+    while H * hd > 512:
+        H //= 2
+    while H * hd < 64:
+        H *= 2
+    d = H * hd
+    ff = int(rs.choice([d, 2 * d, 64, 192, 320]))
+    cfg = dict(version_name=version, n_layers=int(rs.choice([3, 4, 6])), num_heads=H, d_model=d, dim_feedforward=ff,
+               max_sequence_chord=int(rs.choice([40, 300])), total_vf_dim=synthetic.total_vf_dim(1))
+    if version[0] == "1" and rs.rand() < 0.3:
+        cfg["rms_norm"] = True
+    B, S = int(rs.choice([1, 2, 3, 5])), int(rs.choice([300, 300, 120, 17]))
+    T = int(rs.randint(2, 25))
+    P = int(rs.randint(1, min(3, T) + 1))
+    info = dict(case=i, family="V" + version[0], cfg={k: v for k, v in cfg.items() if k != "total_vf_dim"}, B=B, S=S, T=T, P=P)
+    m = cls(**cfg).eval()
+    shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=900 + i, recipe="feedback").items()}
+    m.load_state_dict(sd, strict=False)
+    m = m.cuda()
+    fc = feats_t(synthetic.synthetic_features(B, seed=1100 + i))
+    fc = {k: (v[:, :S].contiguous() if v.dim() > 1 and v.shape[1] == 300 else v) for k, v in fc.items()}
+    f = {k: v.cuda() for k, v in fc.items()}
+    prim = torch.tensor([C.primer_from_name(n) for n in ["C", "A:min", "D:min"][:P]])
+    fails = []
+    with torch.no_grad():
+        for beam in (0, 1):
+            kw = dict(sampler="argmax") if beam == 0 else {}
+            out = m.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], prim[:, 0], prim[:, 1], prim[:, 2],
+                                   target_seq_length=T, beam=beam, **kw).cpu()
+            for b in range(B):
+                one = {k: v[b:b + 1] for k, v in f.items()}
+                gk = dict(feature_semantic_list=one["semantic"], feature_key=one["key"][0], feature_scene_offset=one["scene_offset"],
+                          feature_motion=one["motion"], feature_emotion=one["emotion"], primer=prim[:, 0], primer_root=prim[:, 1],
+                          primer_attr=prim[:, 2], target_seq_length=T, beam=beam, **kw)
+                ref = m.generate(use_cache=False, **gk).cpu()
+                if not torch.equal(out[b:b + 1], ref):
+                    j = int((out[b] != ref[0]).nonzero()[0])
+                    fails.append(f"lockstep vs re-forward beam={beam} clip={b} pos={j} got={int(out[b, j])} want={int(ref[0, j])}")
+                if b == 0 and version[0] != "3":
+                    cached = m.generate(**gk).cpu()
+                    if not torch.equal(cached, ref):
+                        fails.append(f"cached one-clip vs re-forward beam={beam}")
+    info["fails"] = fails
+    del m
+    return info
+
+
+def run_case_modules(i, rs):
+    """The stand-alone modules of configs 4 / 5 at random shapes against the oracle: MultiheadGQA (head_dim 16 ... 128, every kv-head
+    grouping, self- and cross-shaped inputs, causal or not, the (L, B) memory reinterpretation for B > 1) and MoELayer / SharedMoELayer
+    (2 ... 16 experts, top-1 ... top-4, expert widths that are not multiples of 64)."""
+    from video2music_amd.model.grouped_query_attention import MultiheadGQA
+    from video2music_amd.model.moe import GLUExpert, MoELayer, SharedMoELayer
+    fails = []
+    if rs.rand() < 0.5:
+        hd = int(rs.choice([16, 32, 64, 128]))
+        qh = int(rs.choice([1, 2, 4, 8, 16]))
+        while qh * hd > 1024:
+            qh //= 2
+        kvh = int(rs.choice([h for h in (1, 2, 4, 8, 16) if qh % h == 0]))
+        E = qh * hd
+        L, B = int(rs.choice([1, 7, 33, 128, 300, 700])), int(rs.choice([1, 2, 3]))
+        causal = bool(rs.rand() < 0.5)
+        S = L if causal or rs.rand() < 0.5 else int(rs.choice([5, 64, 300]))
+        info = dict(case=i, module="MultiheadGQA", E=E, query_heads=qh, kv_heads=kvh, L=L, S=S, B=B, causal=causal)
+        m = MultiheadGQA(E, qh, kvh).eval()
+        shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+        sd = {k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=40 + i).items()}
+        m.load_state_dict(sd)
+        m = m.cuda()
+        q = torch.from_numpy(rs.standard_normal((L, B, E)).astype(np.float32))
+        kv = q if S == L else torch.from_numpy(rs.standard_normal((S, B, E)).astype(np.float32))
+        ref = O.gqa_forward(q, kv, kv, sd, qh, kvh, is_causal=causal)
+        with torch.no_grad():
+            y, _ = m(q.cuda(), kv.cuda(), kv.cuda(), is_causal=causal)
+        info["err"] = float((y.cpu() - ref).abs().max())
+        info["scale"] = float(ref.abs().max())
+    else:
+        d = int(rs.choice([64, 128, 192, 256, 512]))
+        dff = int(rs.choice([d, 2 * d, 96, 200, 320]))
+        ne = int(rs.choice([2, 4, 6, 8, 16]))
+        k = int(rs.choice([1, 2, 2, 3, 4]))
+        k = min(k, ne)
+        shared = bool(rs.rand() < 0.5)
+        L, B = int(rs.choice([1, 5, 64, 300, 1024])), int(rs.choice([1, 2, 4]))
+        info = dict(case=i, module="SharedMoELayer" if shared else "MoELayer", d=d, dff=dff, n_experts=ne, k=k, L=L, B=B)
+        m = (SharedMoELayer(GLUExpert(d, dff), d, n_experts=ne, n_experts_per_token=k) if shared
+             else MoELayer(GLUExpert(d, dff), d, ne, k)).eval()
+        shapes = [(kk, tuple(v.shape)) for kk, v in m.state_dict().items()]
+        sd = {kk: torch.from_numpy(v) for kk, v in synthetic.synthetic_state_dict(shapes, seed=60 + i).items()}
+        m.load_state_dict(sd)
+        m = m.cuda()
+        x = torch.from_numpy(rs.standard_normal((L, B, d)).astype(np.float32))
+        ref = O.moe_forward(x, sd, ne, k=k, shared=shared)
+        with torch.no_grad():
+            y = m(x.cuda())
+        info["err"] = float((y.cpu() - ref).abs().max())
+        info["scale"] = float(ref.abs().max())
+    if not info["err"] < 1e-4 * max(1.0, info["scale"]):
+        fails.append("output")
+    info["fails"] = fails
+    return info
+
+
+def run_case_reg(i, rs):
+    """VideoRegression (row f2) at random sizes against oracle/reg_oracle.py: the Mamba / BiMamba heads in both gate versions and the
+    recurrent heads, 1-4 layers, clips of 1 ... 300 frames."""
+    from oracle import reg_oracle as R
+    from video2music_amd.model.video_regression import VideoRegression
+    reg = str(rs.choice(["bimamba+", "bimamba", "mamba+", "mamba", "lstm", "bilstm", "gru", "bigru", "cnngru", "cnnbigru"]))
+    rnn = "lstm" in reg or "gru" in reg
+    cfg = dict(n_layers=int(rs.randint(1, 5)), d_model=int(rs.choice([16, 32, 64, 128])),
+               d_hidden=int(rs.choice([16, 32, 64, 128, 256])), total_vf_dim=774, regModel=reg)
+    B, S = int(rs.choice([1, 2, 3])), int(rs.choice([1, 2, 31, 32, 33, 120, 299, 300]))
+    info = dict(case=i, module="VideoRegression", cfg=cfg, B=B, S=S)
+    m = VideoRegression(**cfg).eval()
+    shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=80 + i).items()}
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    f = synthetic.synthetic_features(B, seed=90 + i)
+    sem, emo = torch.from_numpy(f["semantic"][:, :S].copy()), torch.from_numpy(f["emotion"][:, :S].copy())
+    with torch.no_grad():
+        ln_nd, inst = m(sem.cuda(), None, None, emo.cuda())
+    ref_ln, ref_inst = R.forward(sd, sem, emo, reg_model=reg)
+    info["err"] = float(max((ln_nd.cpu() - ref_ln).abs().max(), (inst.cpu() - ref_inst).abs().max()))
+    info["scale"] = float(ref_ln.abs().max())
+    info["fails"] = [] if info["err"] < 1e-4 * max(1.0, info["scale"]) else ["output"]
+    return info
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     if len(sys.argv) > 3 and sys.argv[3] == "v2":
         globals()["run_case"] = run_case_v2
+    if len(sys.argv) > 3 and sys.argv[3] == "reg":
+        globals()["run_case"] = run_case_reg
+    if len(sys.argv) > 3 and sys.argv[3] == "modules":
+        globals()["run_case"] = run_case_modules
+    if len(sys.argv) > 3 and sys.argv[3] == "families":
+        globals()["run_case"] = run_case_families
     rs = np.random.RandomState(seed)
     bad = 0
     t0 = time.time()

@@ -969,7 +969,9 @@ class VideoMusicTransformer_V2(nn.Module):
         st["dff"] = dff
         # amt_v2_step lays its scratch out for one feed-forward width; layers of different widths (V1 '1.3.3' / '1.3.4' with
         # dim_feedforward != 2 d_model) take the same cached step issued operator by operator (`_decode_step`)
-        st["native"] = len(widths) == 1
+        # the step kernels take widths that are multiples of 64 up to 1536 (amt_v2_step / amt_v2_step_batch); other widths take the
+        # operator path too
+        st["native"] = len(widths) == 1 and E % 64 == 0 and dff % 64 == 0 and E <= 1536 and dff <= 1536
         # (one clip may run either step: the one-call step with device-routed experts or the lockstep step with B = 1)
         n_ws = max(_lib.call("amt_v2_step_ws_floats", E, dff, self.n_experts) if nb == 1 else 0,
                    _lib.call("amt_v2_step_batch_ws_floats", E, dff, self.n_experts, nb))
