@@ -146,10 +146,12 @@ def test_top1_branch_in_one_pass_equals_the_step_loop(model1):
     assert a.shape == (4, 80) and torch.equal(a, b) and torch.equal(a[:, :3].cpu(), prim[:, :, 0])
 
 
-def test_shapes_outside_the_fold_fall_back_to_the_plain_chain():
-    """dim_feedforward + d_model > 1536 does not fit the folded skinny GEMM (K <= 1536): the handle silently uses the
+@pytest.mark.parametrize("over", [dict(dim_feedforward=1536), dict(d_model=1024, num_heads=8, dim_feedforward=256, n_layers=1)])
+def test_shapes_outside_the_fold_fall_back_to_the_plain_chain(over):
+    """dim_feedforward + d_model > 1536, or 2 * d_model > 1536 (the folded G1 / G2 read [o | x]: found by the large-shape sweep, which
+    drew d_model 1024 with a narrow feed-forward), does not fit the folded skinny GEMM (K <= 1536): the handle silently uses the
     plain 49-launch chain; ids still equal the oracle's."""
-    cfg = dict(CFG1, dim_feedforward=1536)
+    cfg = dict(CFG1, **over)
     m, sd = build(cfg, seed=4)
     fc = feats_t(synthetic.synthetic_features(1, seed=8))
     f = cu(fc)

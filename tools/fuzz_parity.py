@@ -23,18 +23,30 @@ from video2music_amd.utilities import constants as C
 from tests.helpers import synthetic_sd, feats_t
 
 
+BIG = False          # "big": model widths 576 ... 1024 (the library's upper range, incl. the plain chain beyond d + dff = 1536), up to 40 clips
+
+
 def draw(rs):
     hd = int(rs.choice([16, 32, 64, 128]))
     H = int(rs.choice([1, 2, 3, 4, 8]))
     while H * hd > 512:
         H = max(1, H // 2)
     d = H * hd
+    if BIG:
+        hd = int(rs.choice([64, 128]))
+        H = int(rs.choice([5, 6, 8, 12, 16]))
+        while H * hd > 1024:
+            H -= 1
+        d = H * hd
     ff = int(rs.choice([d, 2 * d, 3 * d, 64, 256 + 64 * int(rs.randint(0, 8))]))
     ff = max(64, min(ff, 1536) // 64 * 64)
     cfg = dict(n_layers=int(rs.randint(1, 4)), num_heads=H, d_model=d, dim_feedforward=ff,
                max_sequence_chord=int(rs.choice([24, 40, 64, 100, 300])), total_vf_dim=synthetic.total_vf_dim(int(rs.randint(0, 2))),
                rpr=bool(rs.rand() < 0.8))
     B = int(rs.choice([1, 1, 2, 3, 5, 7]))
+    if BIG:
+        cfg["n_layers"] = int(rs.randint(1, 3))
+        B = int(rs.choice([1, 2, 33, 40]))
     S = int(rs.choice([300, 300, 1, 2, 17, 120, 299]))
     T = int(rs.randint(2, min(cfg["max_sequence_chord"], 36) + 1))
     P = int(rs.randint(1, min(4, T) + 1))
@@ -76,7 +88,7 @@ def run_case(i, rs):
         with torch.no_grad():
             out = m.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], prim[:, 0], prim[:, 1], prim[:, 2],
                                    target_seq_length=T, beam=beam, **kw).cpu()
-        for b in range(B):
+        for b in (range(B) if B <= 8 else (0, 31, 32, B - 1)):
             one = {k: v[b:b + 1] for k, v in fc.items()}
             ref_ids = O.generate(sd, cfg["num_heads"], one["semantic"], one["key"], one["scene_offset"], one["motion"], one["emotion"],
                                  prim[:, 0], prim[:, 1], prim[:, 2], target_seq_length=T, beam=beam)
@@ -327,6 +339,8 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     if len(sys.argv) > 3 and sys.argv[3] == "v2":
         globals()["run_case"] = run_case_v2
+    if len(sys.argv) > 3 and sys.argv[3] == "big":
+        globals()["BIG"] = True
     if len(sys.argv) > 3 and sys.argv[3] == "reg":
         globals()["run_case"] = run_case_reg
     if len(sys.argv) > 3 and sys.argv[3] == "modules":

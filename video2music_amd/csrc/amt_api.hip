@@ -581,7 +581,7 @@ extern "C" int32_t amt_finalize(amt_handle* h) {
         if ((rc = dev_alloc(h, &h->hb, mb * dff))) return rc;
         // folded chain: K = 2d and dff + d must fit the skinny GEMM, d the attention prologue
         const char* chain = getenv("AMT_DECODE_CHAIN");
-        h->fold = !(chain && strcmp(chain, "plain") == 0) && d % 32 == 0 && d <= 1024 && (dff + d) % 64 == 0 && dff + d <= 1536 && dff % 16 == 0;
+        h->fold = !(chain && strcmp(chain, "plain") == 0) && d % 32 == 0 && 2 * d <= 1536 && (dff + d) % 64 == 0 && dff + d <= 1536 && dff % 16 == 0;   // G1 / G2 read [o | x]: K = 2d
         if (h->fold) {
             if ((rc = dev_alloc(h, &h->qraw, bd))) return rc;
             if ((rc = dev_alloc(h, &h->hraw, mb * dff))) return rc;
