@@ -438,8 +438,8 @@ extern "C" int32_t amt_create(const amt_config* c, amt_handle** out) {
     AMT_CHECK_ARG(c->d_model % c->num_heads == 0, "amt_create: d_model %% num_heads != 0");
     const int hd = c->d_model / c->num_heads;
     AMT_CHECK_ARG(hd == 16 || hd == 32 || hd == 64 || hd == 128, "amt_create: head_dim %d not in {16,32,64,128}", hd);
-    AMT_CHECK_ARG(c->d_model % 64 == 0 && c->d_model <= 1024, "amt_create: d_model must be a multiple of 64 and <= 1024");
-    AMT_CHECK_ARG(c->dim_feedforward % 64 == 0 && c->dim_feedforward <= 1536, "amt_create: dim_feedforward must be a multiple of 64 and <= 1536");
+    AMT_CHECK_ARG(c->d_model % 32 == 0 && c->d_model >= 64 && c->d_model <= 1024, "amt_create: d_model must be a multiple of 32, 64 <= d_model <= 1024");
+    AMT_CHECK_ARG(c->dim_feedforward % 32 == 0 && c->dim_feedforward <= 1536, "amt_create: dim_feedforward must be a multiple of 32 and <= 1536");
     AMT_CHECK_ARG(c->max_batch > 0 && c->max_batch <= 256, "amt_create: max_batch must be in 1..256 (shard larger batches)");
     AMT_CHECK_ARG(c->max_sequence_video > 0 && c->max_sequence_chord > 0 && c->total_vf_dim > 0, "amt_create: bad sequence dims");
     amt_handle* h = new amt_handle();

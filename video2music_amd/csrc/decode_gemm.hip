@@ -551,7 +551,7 @@ int32_t amt_launch_decode_gemm(const DecodeGemmParams& p_in, hipStream_t stream)
     DecodeGemmParams p = p_in;
     if (int32_t zrc = zero_words(&p.zero)) return zrc;
     AMT_CHECK_ARG(p.B > 0 && p.B <= MAXB, "decode_gemm: B=%d outside (0,%d]", p.B, MAXB);
-    AMT_CHECK_ARG(p.K % 64 == 0 && p.K <= 1536, "decode_gemm: K=%d must be a multiple of 64 and <= 1536", p.K);
+    AMT_CHECK_ARG(p.K % 32 == 0 && p.K <= 1536, "decode_gemm: K=%d must be a multiple of 32 and <= 1536", p.K);
     AMT_CHECK_ARG(p.N > 0 && p.ldx % 4 == 0, "decode_gemm: bad N/ldx");
     AMT_CHECK_ARG(p.mode == 0 || (p.kcache && p.vcache && p.d > 0 && p.N == 3 * p.d && p.d == p.H * p.hd), "decode_gemm: bad QKV epilogue");
     if (p.x2) AMT_CHECK_ARG(p.K1 > 0 && p.K1 < p.K && p.K1 % 16 == 0 && p.ldx >= p.K1 && p.ldx2 >= p.K - p.K1 && p.ldx2 % 4 == 0,

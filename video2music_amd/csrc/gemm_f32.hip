@@ -259,7 +259,7 @@ int32_t amt_launch_gemm(const GemmParams& p, hipStream_t stream) {
         const char* f = getenv("AMT_GEMM_SMALL_MN");
         small_mn = f ? atol(f) : 650000;
     }
-    if (p.M <= small_m && (long)p.M * p.N <= small_mn && p.K % 64 == 0 && p.K <= 1536 && !p.head_split && !p.rowadd && !p.silu_mul &&
+    if (p.M <= small_m && (long)p.M * p.N <= small_mn && p.K % 32 == 0 && p.K <= 1536 && !p.head_split && !p.rowadd && !p.silu_mul &&
         !p.sigmoid && !p.tile_group && !p.a_gather && p.relu != 2) {
         DecodeGemmParams g{};
         g.B = p.M; g.eps = 1e-5f; g.x = p.A; g.ldx = p.lda; g.Wp = p.W; g.ldw = p.ldw; g.bias = p.bias; g.N = p.N; g.K = p.K;
