@@ -214,6 +214,65 @@ def run_case_v2(i, rs):
     return info
 
 
+def run_case_options(i, rs):
+    """The base model's rarely used options at random shapes against the oracle: chord_embed / scene_embed (state_dict built like
+    oracle/make_goldens_base_embed.py builds the reference's), forward(mask=False), and generate with beam > 1 / beam_chance < 1 under a seeded
+    python `random` (model/video_music_transformer.py:1074-1084; Categorical replaced by arg-max)."""
+    import random
+    from video2music_amd.utilities.constants import SCENE_OFFSET_MAX
+    cfg, B, S, T, P, recipe = draw(rs)
+    ce, se = bool(rs.rand() < 0.4), bool(rs.rand() < 0.4)
+    cfg["total_vf_dim"] = synthetic.total_vf_dim(1) - int(se)
+    info = dict(case=i, cfg={k: v for k, v in cfg.items() if k != "total_vf_dim"}, chord_embed=ce, scene_embed=se, B=B, S=S, T=T, P=P, recipe=recipe)
+    sd = dict(synthetic_sd(cfg, seed=200 + i, recipe=recipe))
+    if not cfg["rpr"]:
+        sd = {k: v for k, v in sd.items() if not k.endswith(".Er")}
+    if se:
+        sd["scene_embedding.weight"] = torch.from_numpy(synthetic.fill_tensor("scene_embedding.weight", (SCENE_OFFSET_MAX, cfg["d_model"]), 200 + i))
+    if ce:
+        sd["chord_embedding_model.weight"] = torch.from_numpy(synthetic.fill_tensor("chord_embedding_model.weight", (159, cfg["d_model"]), 200 + i))
+    m = VideoMusicTransformer(**cfg, chord_embed=ce, scene_embed=se).eval()
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith(".pe") for k in missing), (missing, unexpected)
+    m = m.cuda()
+    fc = feats_t(synthetic.synthetic_features(B, seed=600 + i))
+    fc = {k: (v[:, :S].contiguous() if v.dim() > 1 and v.shape[1] == 300 else v) for k, v in fc.items()}
+    f = {k: v.cuda() for k, v in fc.items()}
+    fails = []
+    H = cfg["num_heads"]
+    L = int(rs.randint(1, T + 1))
+    ids = torch.from_numpy(rs.randint(0, 157, size=(B, L)))
+    root = torch.from_numpy(rs.randint(0, 13, size=(B, L)))
+    attr = torch.from_numpy(rs.randint(0, 14, size=(B, L)))
+    for mask in (True, False):
+        with torch.no_grad():
+            ref = O.forward(sd, H, ids if ce else root, attr, fc["semantic"], fc["key"], fc["scene_offset"], fc["motion"], fc["emotion"], mask=mask)
+            got = m(ids.cuda(), root.cuda(), attr.cuda(), f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], mask=mask).cpu()
+        err = float((got - ref).abs().max())
+        info["fwd_err" if mask else "fwd_nomask_err"] = err
+        if not err < 1e-3:
+            fails.append("forward mask=%s" % mask)
+    prim = torch.tensor([C.primer_from_name(n) for n in ["C", "A:min", "D:min", "G"][:P]])
+    for beam, chance in ((0, 1.0), (1, 1.0), (int(rs.randint(2, 5)), float(rs.choice([1.0, 0.5]))), (1, 0.4)):
+        if ce and beam > 1:
+            continue                                   # the reference itself fails there (cross-attention shape at the second step)
+        one = {k: v[:1] for k, v in fc.items()}
+        seed = int(rs.randint(0, 10000))
+        ref_ids = O.generate(sd, H, one["semantic"], one["key"], one["scene_offset"], one["motion"], one["emotion"], prim[:, 0], prim[:, 1], prim[:, 2],
+                             target_seq_length=T, beam=beam, beam_chance=chance, rng=random.Random(seed))
+        random.seed(seed)
+        with torch.no_grad():
+            out = m.generate(feature_semantic_list=f["semantic"][:1], feature_key=f["key"][0], feature_scene_offset=f["scene_offset"][:1],
+                             feature_motion=f["motion"][:1], feature_emotion=f["emotion"][:1], primer=prim[:, 0], primer_root=prim[:, 1],
+                             primer_attr=prim[:, 2], target_seq_length=T, beam=beam, beam_chance=chance, sampler="argmax").cpu()
+        if out.shape != ref_ids.shape or not torch.equal(out, ref_ids):
+            fails.append(f"generate beam={beam} chance={chance}: shape {tuple(out.shape)} vs {tuple(ref_ids.shape)}"
+                         + ("" if out.shape != ref_ids.shape else f" first diff at {[int(v) for v in (out != ref_ids).nonzero()[0]]}"))
+    info["fails"] = fails
+    del m
+    return info
+
+
 def run_case_families(i, rs):
     """V1 ('1.0' ... '1.3.4', rms_norm on / off), V2 ('2.0', '2.1', '2.2') and V3 ('3.0' - '3.2') at random shapes.  The oracle holds
     only V2 '2.2'; the other families are pinned by goldens of the reference classes at their default shapes (tests/golden/g_v1, g_v2_variants,
@@ -364,6 +423,8 @@ def main():
         globals()["LONG"] = True
     if len(sys.argv) > 3 and sys.argv[3] == "odd":
         globals()["ODD"] = True
+    if len(sys.argv) > 3 and sys.argv[3] == "options":
+        globals()["run_case"] = run_case_options
     if len(sys.argv) > 3 and sys.argv[3] == "big":
         globals()["BIG"] = True
     if len(sys.argv) > 3 and sys.argv[3] == "reg":

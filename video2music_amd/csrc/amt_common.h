@@ -22,6 +22,7 @@ void amt_set_error(const char* fmt, ...);
         hipError_t e__ = (expr);                                                       \
         if (e__ != hipSuccess) {                                                       \
             amt_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            (void)hipGetLastError();   /* reported here: the next call's launch check must not see it again */ \
             return (int32_t)e__;                                                       \
         }                                                                              \
     } while (0)
