@@ -52,6 +52,9 @@ const char* amt_last_error(void);
 int32_t amt_abi_version(void);
 
 /* ---- model lifetime -------------------------------------------------------------------- */
+/* Shapes the handle takes (anything else is refused with a message, never computed wrongly): d_model a multiple of 32 with
+ * 64 <= d_model <= 1024; head_dim = d_model / num_heads in {16, 32, 64, 128}; dim_feedforward a multiple of 32, <= 1536;
+ * max_batch 1..256 clips per decode chain (larger batches are sliced by the caller, video2music_amd/model). */
 int32_t amt_create(const amt_config* cfg, amt_handle** out);
 int32_t amt_destroy(amt_handle* h);
 /* One state_dict entry (reference key names).  `data` may be a host or a
