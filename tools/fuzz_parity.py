@@ -145,6 +145,18 @@ def run_case(i, rs):
         info["decode_vs_forward"] = float((fwd[:, P - 1:T - 1].permute(1, 0, 2) - dec).abs().max())
         if not info["decode_vs_forward"] < 1e-3:      # BASELINE.json's logit tolerance (observed: <= 3.4e-4 on logits of magnitude ~100)
             fails.append("decode_vs_forward")
+    # the Categorical draw done on the device: every id must be the inverse CDF of the reference's decision distribution at its uniform
+    if T > P and mcc >= 1:
+        from tests.test_model_gpu import _check_draws
+        u = torch.from_numpy(rs.rand(T, B).astype(np.float32))
+        with torch.no_grad():
+            tk, lgc = m.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], pb(0), pb(1), pb(2),
+                                       target_seq_length=T, beam=0, sampler="categorical", uniforms=u, return_logits=True,
+                                       max_conseq_N=mcn, max_conseq_chord=mcc)
+        try:
+            _check_draws(tk, lgc, u, P, mcn, mcc)
+        except AssertionError as e:
+            fails.append(f"categorical draw {str(e)[:120]}")
     info["fails"] = fails
     del m
     return info
