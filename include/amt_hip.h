@@ -244,6 +244,14 @@ int32_t amt_moe_fwd(const float* x, const float* gate_w, const float* gate_b,
                     const float* sw1, const float* sb1, const float* swg, const float* sbg, const float* sw2, const float* sb2,
                     float* out, int32_t* idx_out, float* w_out, float* scratch,
                     int32_t n_tok, int32_t d, int32_t dff, int32_t n_exp, void* stream);
+/* The same layer with n_experts_per_token = k, 1 <= k <= 8 (MoELayer / SharedMoELayer constructor argument, moe.py:150-160,202-215; every
+ * reference model passes 2): idx_out / w_out are (n_tok, k), the shared expert enters with 1/k; scratch from amt_moe_topk_scratch_floats. */
+int64_t amt_moe_topk_scratch_floats(int32_t n_tok, int32_t d, int32_t dff, int32_t n_exp, int32_t k);
+int32_t amt_moe_topk_fwd(const float* x, const float* gate_w, const float* gate_b,
+                    const float* w1, const float* b1, const float* wg, const float* bg, const float* w2, const float* b2,
+                    const float* sw1, const float* sb1, const float* swg, const float* sbg, const float* sw2, const float* sb2,
+                    float* out, int32_t* idx_out, float* w_out, float* scratch,
+                    int32_t n_tok, int32_t d, int32_t dff, int32_t n_exp, int32_t k, void* stream);
 
 /* Pieces of the same layer for expert-parallel execution (config 5: one expert group per GPU; the token rows
  * travel by all_to_all between amt_moe_route_fwd and amt_moe_combine_fwd, see video2music_amd/model/moe.py):

@@ -70,6 +70,28 @@ def test_gqa_head_dim_16_vs_oracle():
         assert err < TOL, (L, B, causal, err)
 
 
+@pytest.mark.parametrize("shared,n_exp,k", [(False, 8, 1), (True, 6, 3), (False, 4, 4), (True, 16, 5)])
+def test_moe_other_top_k_vs_oracle(shared, n_exp, k):
+    """MoELayer / SharedMoELayer with n_experts_per_token other than the class default of 2 (moe.py:150-160: `torch.topk(logits, k)`, softmax over
+    the k logits, accumulation in expert order, shared expert / k): routing ids and weights and the output against the oracle."""
+    from video2music_amd.model.moe import GLUExpert, MoELayer, SharedMoELayer
+    d, dff = 128, 192
+    m = (SharedMoELayer(GLUExpert(d, dff), d, n_experts=n_exp, n_experts_per_token=k) if shared else MoELayer(GLUExpert(d, dff), d, n_exp, k)).eval()
+    shapes = [(kk, tuple(v.shape)) for kk, v in m.state_dict().items()]
+    sd = {kk: torch.from_numpy(v) for kk, v in synthetic.synthetic_state_dict(shapes, seed=11 + k).items()}
+    m.load_state_dict(sd)
+    m = m.cuda()
+    x = torch.from_numpy(np.random.RandomState(k).standard_normal((70, 3, d)).astype(np.float32))
+    routing = {}
+    ref = O.moe_forward(x, sd, n_exp, k=k, shared=shared, routing=routing)
+    with torch.no_grad():
+        y = m(x.cuda())
+    assert (y.cpu() - ref).abs().max().item() < TOL
+    idx, wts = m.last_routing
+    assert idx.shape == (70, 3, k) and torch.equal(idx.cpu().long(), routing["idx"])
+    assert (wts.cpu() - routing["weights"]).abs().max().item() < 1e-6
+
+
 @pytest.mark.parametrize("name", ["moe", "shared"])
 def test_moe_vs_reference_golden(golden, name):
     g = golden("g_moe.npz")

@@ -72,6 +72,8 @@ SIGNATURES = {
     "amt_gqa_fwd": [_P] * 15 + [_I] * 7 + [_F, _P],
     "amt_moe_scratch_floats": [_I, _I, _I, _I],
     "amt_moe_fwd": [_P] * 19 + [_I] * 4 + [_P],
+    "amt_moe_topk_scratch_floats": [_I, _I, _I, _I, _I],
+    "amt_moe_topk_fwd": [_P] * 19 + [_I] * 5 + [_P],
     "amt_moe_route_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "amt_glu_expert_fwd": [_P] * 9 + [_I, _I, _I, _P],
     "amt_moe_combine_fwd": [_P, _P, _P, _P, _P, _F, _P, _I, _I, _P],
@@ -87,7 +89,7 @@ SIGNATURES = {
     "amt_v2_step_batch_ws_floats": [_I, _I, _I, _I],
     "amt_v2_step_batch": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
 }
-_RESTYPES = {"amt_last_error": C.c_char_p, "amt_decode_step_bytes": C.c_int64, "amt_moe_scratch_floats": C.c_int64,
+_RESTYPES = {"amt_last_error": C.c_char_p, "amt_decode_step_bytes": C.c_int64, "amt_moe_scratch_floats": C.c_int64, "amt_moe_topk_scratch_floats": C.c_int64,
              "amt_v2_step_ws_floats": C.c_int64, "amt_v2_step_batch_ws_floats": C.c_int64}
 _NO_STATUS = set(_RESTYPES) | {"amt_abi_version"}
 

@@ -52,6 +52,76 @@ __global__ __launch_bounds__(256) void moe_route_kernel(const float* __restrict_
     }
 }
 
+// top-k routing for k other than the class default of 2 (MoELayer(n_experts_per_token=k), moe.py:150-200): the k largest gate logits,
+// largest first and the lower expert id first among equals like torch.topk, softmax over those k (fp32, max subtracted)
+constexpr int KMAX = 8;
+__global__ __launch_bounds__(256) void moe_route_k_kernel(const float* __restrict__ x, const float* __restrict__ gw,
+                                                          const float* __restrict__ gb, int n_tok, int d, int n_exp, int k,
+                                                          int* __restrict__ idx, float* __restrict__ wts) {
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= n_tok) return;
+    const float* xrow = x + (size_t)tok * d;
+    float bv[KMAX];
+    int bi[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) { bv[j] = -INFINITY; bi[j] = 0; }
+    for (int e = 0; e < n_exp; ++e) {
+        float s = 0.f;
+        for (int c = lane * 4; c < d; c += 256) {
+            const float4 a = ld4(xrow + c), w = ld4(gw + (size_t)e * d + c);
+            s += a.x * w.x + a.y * w.y + a.z * w.z + a.w * w.w;
+        }
+        s = wave_sum(s) + (gb ? gb[e] : 0.f);
+        // insert into the sorted list (strictly greater moves ahead: equal logits keep the lower expert id first)
+        float cv = s;
+        int ci = e;
+        bool ins = false;                           // once inserted, everything below moves down one place
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+            if (j < k && (ins || cv > bv[j])) {
+                const float tv = bv[j]; const int ti = bi[j];
+                bv[j] = cv; bi[j] = ci; cv = tv; ci = ti;
+                ins = true;
+            }
+        }
+    }
+    float sum = 0.f, ev[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) { ev[j] = j < k ? __expf(bv[j] - bv[0]) : 0.f; sum += ev[j]; }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j)
+            if (j < k) { idx[tok * k + j] = bi[j]; wts[tok * k + j] = ev[j] / sum; }
+    }
+}
+
+// combine for k != 2: the token's k expert rows in expert-index order (moe.py:191-199), then shared / k
+__global__ void moe_combine_k_kernel(const float* __restrict__ Y, const int* __restrict__ slot_pos, const int* __restrict__ idx,
+                                     const float* __restrict__ wts, const float* __restrict__ shared, float shared_scale,
+                                     float* __restrict__ out, int d, int k) {
+    const int tok = blockIdx.x;
+    int ord[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) ord[j] = j;
+    for (int a = 1; a < k; ++a)                     // insertion sort of the k slots by expert id (k <= 8, uniform per block)
+        for (int b = a; b > 0 && idx[tok * k + ord[b]] < idx[tok * k + ord[b - 1]]; --b) { const int t = ord[b]; ord[b] = ord[b - 1]; ord[b - 1] = t; }
+    for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < k; ++j) {
+            const int sl = tok * k + ord[j];
+            const float w = wts[sl];
+            const float4 y = ld4(Y + (size_t)slot_pos[sl] * d + c);
+            o.x += w * y.x; o.y += w * y.y; o.z += w * y.z; o.w += w * y.w;
+        }
+        if (shared) {
+            const float4 sh = ld4(shared + (size_t)tok * d + c);
+            o.x += shared_scale * sh.x; o.y += shared_scale * sh.y; o.z += shared_scale * sh.z; o.w += shared_scale * sh.w;
+        }
+        st4(out + (size_t)tok * d + c, o);
+    }
+}
+
 // plan, three small launches (counts -> 128-aligned segment offsets -> placement).  Rows of one expert may land in
 // any order inside its segment: every output row is computed independently, so the values do not depend on it.
 __global__ __launch_bounds__(256) void moe_count_kernel(const int* __restrict__ idx, int n_assign, int* __restrict__ counts) {
@@ -89,7 +159,7 @@ __global__ __launch_bounds__(1024) void moe_offsets_kernel(int* __restrict__ cou
 }
 
 __global__ __launch_bounds__(256) void moe_place_kernel(const int* __restrict__ idx, int n_assign, const int* __restrict__ offsets,
-                                                        int* __restrict__ cursors, int* __restrict__ perm, int* __restrict__ slot_pos) {
+                                                        int* __restrict__ cursors, int* __restrict__ perm, int* __restrict__ slot_pos, int k) {
     __shared__ int c[64], base[64];
     if (threadIdx.x < 64) c[threadIdx.x] = 0;
     __syncthreads();
@@ -101,7 +171,7 @@ __global__ __launch_bounds__(256) void moe_place_kernel(const int* __restrict__ 
     __syncthreads();
     if (e >= 0) {
         const int pos = offsets[e] + base[e] + local;
-        perm[pos] = i >> 1;
+        perm[pos] = i / k;
         slot_pos[i] = pos;
     }
 }
@@ -177,23 +247,27 @@ inline size_t align4(size_t n) { return (n + 3) / 4 * 4; }
 
 }  // namespace
 
-extern "C" int64_t amt_moe_scratch_floats(int32_t n_tok, int32_t d, int32_t dff, int32_t n_exp) {
-    const size_t Mp = ((size_t)2 * n_tok + TILE - 1) / TILE * TILE + (size_t)TILE * n_exp;
+extern "C" int64_t amt_moe_topk_scratch_floats(int32_t n_tok, int32_t d, int32_t dff, int32_t n_exp, int32_t k) {
+    const size_t Mp = ((size_t)k * n_tok + TILE - 1) / TILE * TILE + (size_t)TILE * n_exp;
     // G, H : Mp x dff ; Y : Mp x d ; shared G,H : n_tok x dff ; shared Y : n_tok x d ; ints: perm, slot_pos, tile_group
     return (int64_t)(2 * Mp * dff + Mp * d + 2 * (size_t)n_tok * dff + (size_t)n_tok * d +
-                     align4(Mp) + 3 * align4(2 * (size_t)n_tok) + align4(Mp / TILE + 1) + 256 + 64);
+                     align4(Mp) + 3 * align4(k * (size_t)n_tok) + align4(Mp / TILE + 1) + 256 + 64);
+}
+extern "C" int64_t amt_moe_scratch_floats(int32_t n_tok, int32_t d, int32_t dff, int32_t n_exp) {
+    return amt_moe_topk_scratch_floats(n_tok, d, dff, n_exp, 2);
 }
 
-extern "C" int32_t amt_moe_fwd(const float* x, const float* gate_w, const float* gate_b,
-                               const float* w1, const float* b1, const float* wg, const float* bg, const float* w2, const float* b2,
-                               const float* sw1, const float* sb1, const float* swg, const float* sbg, const float* sw2, const float* sb2,
-                               float* out, int32_t* idx_out, float* w_out, float* scratch,
-                               int32_t n_tok, int32_t d, int32_t dff, int32_t n_exp, void* stream) {
+static int32_t moe_fwd_impl(const float* x, const float* gate_w, const float* gate_b,
+                            const float* w1, const float* b1, const float* wg, const float* bg, const float* w2, const float* b2,
+                            const float* sw1, const float* sb1, const float* swg, const float* sbg, const float* sw2, const float* sb2,
+                            float* out, int32_t* idx_out, float* w_out, float* scratch,
+                            int32_t n_tok, int32_t d, int32_t dff, int32_t n_exp, int32_t k, void* stream) {
     AMT_CHECK_ARG(x && gate_w && wg && w2 && out && scratch, "amt_moe_fwd: null pointer");
     AMT_CHECK_ARG(n_tok > 0 && n_exp >= 2 && n_exp <= 64, "amt_moe_fwd: need 2 <= n_experts <= 64");
+    AMT_CHECK_ARG(k >= 1 && k <= KMAX && k <= n_exp, "amt_moe_fwd: n_experts_per_token=%d outside 1..min(%d, n_experts)", k, KMAX);
     AMT_CHECK_ARG(d % 32 == 0 && dff % 32 == 0, "amt_moe_fwd: d and d_ff must be multiples of 32");
     hipStream_t s = (hipStream_t)stream;
-    const int Mp = (2 * n_tok + TILE - 1) / TILE * TILE + TILE * n_exp;     // multiple of the row tile
+    const int Mp = (k * n_tok + TILE - 1) / TILE * TILE + TILE * n_exp;     // multiple of the row tile
     float* G = scratch;
     float* Hh = G + (size_t)Mp * dff;
     float* Y = Hh + (size_t)Mp * dff;
@@ -202,19 +276,20 @@ extern "C" int32_t amt_moe_fwd(const float* x, const float* gate_w, const float*
     float* Ys = Hs + (size_t)n_tok * dff;
     int* perm = (int*)(Ys + (size_t)n_tok * d);
     int* slot_pos = perm + align4(Mp);
-    int* tile_group = slot_pos + align4(2 * (size_t)n_tok);
+    int* tile_group = slot_pos + align4(k * (size_t)n_tok);
     int* idx = tile_group + align4(Mp / TILE + 1);
-    float* wts = (float*)(idx + align4(2 * (size_t)n_tok));
-    int* plan_ints = (int*)(wts + align4(2 * (size_t)n_tok));     // [0..63] counts, [64..128] offsets, [192..255] cursors
+    float* wts = (float*)(idx + align4(k * (size_t)n_tok));
+    int* plan_ints = (int*)(wts + align4(k * (size_t)n_tok));     // [0..63] counts, [64..128] offsets, [192..255] cursors
     if (idx_out) idx = idx_out;
     if (w_out) wts = w_out;
     AMT_HIP(hipMemsetAsync(plan_ints, 0, 64 * sizeof(int), s));
 
-    hipLaunchKernelGGL(moe_route_kernel, dim3(cdiv(n_tok, 4)), dim3(256), 0, s, x, gate_w, gate_b, n_tok, d, n_exp, idx, wts);
+    if (k == 2) hipLaunchKernelGGL(moe_route_kernel, dim3(cdiv(n_tok, 4)), dim3(256), 0, s, x, gate_w, gate_b, n_tok, d, n_exp, idx, wts);
+    else hipLaunchKernelGGL(moe_route_k_kernel, dim3(cdiv(n_tok, 4)), dim3(256), 0, s, x, gate_w, gate_b, n_tok, d, n_exp, k, idx, wts);
     AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(moe_count_kernel, dim3(cdiv(2 * n_tok, 256)), dim3(256), 0, s, idx, 2 * n_tok, plan_ints);
+    hipLaunchKernelGGL(moe_count_kernel, dim3(cdiv(k * n_tok, 256)), dim3(256), 0, s, idx, k * n_tok, plan_ints);
     hipLaunchKernelGGL(moe_offsets_kernel, dim3(1), dim3(1024), 0, s, plan_ints, plan_ints + 64, plan_ints + 192, n_exp, perm, tile_group, Mp);
-    hipLaunchKernelGGL(moe_place_kernel, dim3(cdiv(2 * n_tok, 256)), dim3(256), 0, s, idx, 2 * n_tok, plan_ints + 64, plan_ints + 192, perm, slot_pos);
+    hipLaunchKernelGGL(moe_place_kernel, dim3(cdiv(k * n_tok, 256)), dim3(256), 0, s, idx, k * n_tok, plan_ints + 64, plan_ints + 192, perm, slot_pos, k);
     AMT_LAUNCH_CHECK();
     int32_t rc;
     // gate branch: G = x_e . Wg[e]^T + bg[e]
@@ -249,9 +324,26 @@ extern "C" int32_t amt_moe_fwd(const float* x, const float* gate_w, const float*
         if ((rc = amt_launch_gemm(c, s))) return rc;
         shared = Ys;
     }
-    hipLaunchKernelGGL(moe_combine_kernel, dim3(n_tok), dim3(128), 0, s, Y, slot_pos, idx, wts, shared, 0.5f, out, d);
+    if (k == 2) hipLaunchKernelGGL(moe_combine_kernel, dim3(n_tok), dim3(128), 0, s, Y, slot_pos, idx, wts, shared, 0.5f, out, d);
+    else hipLaunchKernelGGL(moe_combine_k_kernel, dim3(n_tok), dim3(128), 0, s, Y, slot_pos, idx, wts, shared, 1.0f / (float)k, out, d, k);
     AMT_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int32_t amt_moe_fwd(const float* x, const float* gate_w, const float* gate_b,
+                               const float* w1, const float* b1, const float* wg, const float* bg, const float* w2, const float* b2,
+                               const float* sw1, const float* sb1, const float* swg, const float* sbg, const float* sw2, const float* sb2,
+                               float* out, int32_t* idx_out, float* w_out, float* scratch,
+                               int32_t n_tok, int32_t d, int32_t dff, int32_t n_exp, void* stream) {
+    return moe_fwd_impl(x, gate_w, gate_b, w1, b1, wg, bg, w2, b2, sw1, sb1, swg, sbg, sw2, sb2, out, idx_out, w_out, scratch, n_tok, d, dff, n_exp, 2, stream);
+}
+// the same layer with n_experts_per_token = k (1 <= k <= 8): idx_out / w_out are (n_tok, k); scratch from amt_moe_topk_scratch_floats
+extern "C" int32_t amt_moe_topk_fwd(const float* x, const float* gate_w, const float* gate_b,
+                                    const float* w1, const float* b1, const float* wg, const float* bg, const float* w2, const float* b2,
+                                    const float* sw1, const float* sb1, const float* swg, const float* sbg, const float* sw2, const float* sb2,
+                                    float* out, int32_t* idx_out, float* w_out, float* scratch,
+                                    int32_t n_tok, int32_t d, int32_t dff, int32_t n_exp, int32_t k, void* stream) {
+    return moe_fwd_impl(x, gate_w, gate_b, w1, b1, wg, bg, w2, b2, sw1, sb1, swg, sbg, sw2, sb2, out, idx_out, w_out, scratch, n_tok, d, dff, n_exp, k, stream);
 }
 
 // ---- pieces of the MoE layer for expert-parallel execution (video2music_amd/model/moe.py: route on every rank,

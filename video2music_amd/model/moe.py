@@ -242,9 +242,12 @@ class _MoEBase(nn.Module):
             raise ValueError("MoE layers take (L, B, d) input (moe.py:193,292 unpack three indices)")
         if x.device.type != "cuda":
             raise _lib.AmtError("MoE layers run on an MI355X only; video2music_amd has no CPU fallback")
-        if self.n_experts_per_token != 2:
-            raise NotImplementedError("the gfx950 MoE path is built for top-2 routing (class default)")
+        k = int(self.n_experts_per_token)
+        if not 1 <= k <= min(8, self.n_experts):
+            raise NotImplementedError(f"n_experts_per_token={k}: the gfx950 MoE path routes to 1..8 experts per token")
         if self.expert_parallel:
+            if k != 2:
+                raise NotImplementedError("expert-parallel execution is built for top-2 routing (the class default)")
             return self._run_ep(x)
         L, B, d = x.shape
         n_tok, n_exp = L * B, self.n_experts
@@ -256,18 +259,18 @@ class _MoEBase(nn.Module):
         if self.shared:
             sh = expert_tensors(self.shared_expert)
         out = torch.empty(n_tok, d, device=x.device, dtype=torch.float32)
-        idx = torch.empty(n_tok, 2, device=x.device, dtype=torch.int32)
-        wts = torch.empty(n_tok, 2, device=x.device, dtype=torch.float32)
-        scratch = torch.empty(_lib.call("amt_moe_scratch_floats", n_tok, d, dff, n_exp), device=x.device, dtype=torch.float32)
+        idx = torch.empty(n_tok, k, device=x.device, dtype=torch.int32)
+        wts = torch.empty(n_tok, k, device=x.device, dtype=torch.float32)
+        scratch = torch.empty(_lib.call("amt_moe_topk_scratch_floats", n_tok, d, dff, n_exp, k), device=x.device, dtype=torch.float32)
         gw, gb = self.gate.weight.detach().contiguous(), self.gate.bias.detach().contiguous()
         t = self._temperature()
         if t != 1.0:
             # softmax(top-2 logits / t) (moe.py:288): the top-2 of logits / t are the top-2 of the logits, so the temperature is
             # folded into the router's weight and bias
             gw, gb = (gw / t).contiguous(), (gb / t).contiguous()
-        _lib.call("amt_moe_fwd", p(xf), p(gw), p(gb), p(w1), p(b1), p(wg), p(bg), p(w2), p(b2),
-                  *[p(t) for t in sh], p(out), p(idx), p(wts), p(scratch), n_tok, d, dff, n_exp, _lib.stream_ptr())
-        self.last_routing = (idx.view(L, B, 2), wts.view(L, B, 2))
+        _lib.call("amt_moe_topk_fwd", p(xf), p(gw), p(gb), p(w1), p(b1), p(wg), p(bg), p(w2), p(b2),
+                  *[p(t) for t in sh], p(out), p(idx), p(wts), p(scratch), n_tok, d, dff, n_exp, k, _lib.stream_ptr())
+        self.last_routing = (idx.view(L, B, k), wts.view(L, B, k))
         return out.view(L, B, d)
 
 
