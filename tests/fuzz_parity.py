@@ -1,11 +1,11 @@
-"""Randomised parity sweep of the HIP path against the CPU oracle (test infrastructure, GPU box only).
+"""Randomised parity sweep of the HIP path against the CPU oracle (test infrastructure -- it lives under tests/ because it drives the oracle --, GPU box only).
 
 Draws model shapes, batch sizes, clip lengths, primer lengths and target lengths at random (seeded), and for every draw compares
   * the teacher-forced forward logits with oracle.forward (<= 1e-3, BASELINE.json's tolerance),
   * the feedback-greedy ids (beam=0, argmax = oracle G2) and the top-1 ids (beam=1 = oracle G1) of every clip with oracle.generate;
     an id mismatch is only accepted as a near-tie when the oracle's own top-1 / top-2 margin at the first differing position is below 1e-4,
   * the decode-path logits with the forward's on the generated sequence (<= 1e-3, as for the forward).
-Usage: python tools/fuzz_parity.py [n_cases] [seed] [v2]      -> one JSON line per case (third argument v2: the V2 '2.2' family against the oracle; families: V1 / V2 / V3 cached decode against their own re-forward; modules: MultiheadGQA / MoELayer / SharedMoELayer against the oracle; reg: VideoRegression against oracle/reg_oracle.py), a summary at the end, exit 1 on any failure.
+Usage: python tests/fuzz_parity.py [n_cases] [seed] [v2]      -> one JSON line per case (third argument v2: the V2 '2.2' family against the oracle; families: V1 / V2 / V3 cached decode against their own re-forward; modules: MultiheadGQA / MoELayer / SharedMoELayer against the oracle; reg: VideoRegression against oracle/reg_oracle.py), a summary at the end, exit 1 on any failure.
 """
 import json
 import os
@@ -305,6 +305,11 @@ def run_case_families(i, rs):
                max_sequence_chord=int(rs.choice([40, 300])), total_vf_dim=synthetic.total_vf_dim(1))
     if version[0] == "1" and rs.rand() < 0.3:
         cfg["rms_norm"] = True
+    if rs.rand() < 0.3:
+        cfg["chord_embed"] = True                     # chord ids through a frozen table; the ids themselves feed back
+    if rs.rand() < 0.3:
+        cfg["scene_embed"] = True                     # scene offsets through an embedding instead of a feature column
+        cfg["total_vf_dim"] = synthetic.total_vf_dim(1) - 1
     B, S = int(rs.choice([1, 2, 3, 5])), int(rs.choice([300, 300, 120, 17]))
     T = int(rs.randint(2, 25))
     P = int(rs.randint(1, min(3, T) + 1))

@@ -1,11 +1,11 @@
-"""A seeded slice of the randomised parity sweep (tools/fuzz_parity.py) inside the GPU suite: random model shapes (head_dim 16 / 32 / 64 / 128,
+"""A seeded slice of the randomised parity sweep (tests/fuzz_parity.py) inside the GPU suite: random model shapes (head_dim 16 / 32 / 64 / 128,
 1-3 layers, rpr on / off, both motion feature widths), batch sizes, clip lengths (1 ... 300 frames), primer and target lengths; forward logits,
 G1 / G2 ids of every clip and the decode-path logits against the CPU oracle.  The full sweep (100 draws, profiles/r02_fuzz_parity.json) is a
 tool run; shapes outside the library's documented caps must be REFUSED with a message, never computed wrongly."""
 import numpy as np
 import pytest
 
-from tools import fuzz_parity
+from tests import fuzz_parity
 
 pytestmark = pytest.mark.gpu
 

@@ -285,7 +285,7 @@ def test_v2_at_bench_width_vs_reference_golden(golden):
 @pytest.mark.parametrize("d,H,ff,nl", [(256, 4, 64, 4), (512, 4, 192, 3), (32, 1, 320, 3)])     # d_model 32: outside the step kernels' widths
 def test_v2_feed_forward_narrower_than_half_the_model_width(d, H, ff, nl):
     """2 * dim_feedforward < d_model: the stacked gate | up product of a GLU layer then has fewer column tiles than its LayerNorm
-    prologue has 16-column blocks to publish as the block's residual (found by tools/fuzz_parity.py v2: columns past 2 * d_ff of the
+    prologue has 16-column blocks to publish as the block's residual (found by tests/fuzz_parity.py v2: columns past 2 * d_ff of the
     residual were never written).  Lockstep generate_batch and the one-clip generate against the oracle, clip by clip.  A model width
     that is not a multiple of 64 takes the cached step operator by operator instead of being refused at generate time."""
     cfg = dict(CFG_V2, version_name="2.2", n_layers=nl, num_heads=H, d_model=d, dim_feedforward=ff)
