@@ -357,6 +357,33 @@ def test_long_primer_short_video_and_batch_slicing(model1):
     assert (lg[33:34] - lg1).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("msv,S,B", [(500, 450, 2), (64, 40, 3), (1024, 1000, 1)])
+def test_other_max_sequence_video(msv, S, B):
+    """max_sequence_video other than the callers' 300 (the cross-attention key capacity and the video positional table follow it): clips of
+    40 ... 1000 frames, ids and forward logits against the oracle."""
+    cfg = dict(CFG1, max_sequence_video=msv)
+    m = VideoMusicTransformer(**cfg).eval()
+    sd = synthetic_sd(cfg, seed=msv, recipe="feedback")
+    m.load_state_dict(sd, strict=False)
+    m = m.cuda()
+    fc = feats_t(synthetic.synthetic_features(B, seed=msv, n_frames=S))
+    f = cu(fc)
+    pr, prr, pra = (torch.tensor([v]) for v in C.primer_from_name("C"))
+    T = 14
+    out = m.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], pr, prr, pra, target_seq_length=T, beam=0,
+                           sampler="argmax").cpu()
+    for b in range(B):
+        one = {k: v[b:b + 1] for k, v in fc.items()}
+        ref = O.generate(sd, 4, one["semantic"], one["key"], one["scene_offset"], one["motion"], one["emotion"], pr, prr, pra, target_seq_length=T, beam=0)
+        assert torch.equal(out[b:b + 1], ref), (b, out[b], ref)
+    rs = np.random.RandomState(1)
+    root, attr = torch.from_numpy(rs.randint(0, 13, size=(B, 9))), torch.from_numpy(rs.randint(0, 14, size=(B, 9)))
+    with torch.no_grad():
+        lg = m(root, root.cuda(), attr.cuda(), f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"]).cpu()
+    ref = O.forward(sd, 4, root, attr, fc["semantic"], fc["key"], fc["scene_offset"], fc["motion"], fc["emotion"])
+    assert (lg - ref).abs().max().item() < LOGIT_TOL
+
+
 def test_scalar_motion_feature_width():
     """motion_type 0: feature_motion is (B,S) and total_vf_dim = 776 (generate.py:146-149, forward :1012-1015)."""
     cfg = dict(CFG1, total_vf_dim=synthetic.total_vf_dim(0))
