@@ -311,6 +311,9 @@ def run_case_families(i, rs):
         cfg["scene_embed"] = True                     # scene offsets through an embedding instead of a feature column
         cfg["total_vf_dim"] = synthetic.total_vf_dim(1) - 1
     B, S = int(rs.choice([1, 2, 3, 5])), int(rs.choice([300, 300, 120, 17]))
+    msv = int(rs.choice([300, 300, 64, 400]))          # max_sequence_video: video positional table / RoPE cache length
+    cfg["max_sequence_video"] = msv
+    S = min(S, msv) if msv < 300 else (int(rs.choice([S, 350])) if msv > 300 else S)
     T = int(rs.randint(2, 25))
     P = int(rs.randint(1, min(3, T) + 1))
     info = dict(case=i, family="V" + version[0], cfg={k: v for k, v in cfg.items() if k != "total_vf_dim"}, B=B, S=S, T=T, P=P)
@@ -319,8 +322,7 @@ def run_case_families(i, rs):
     sd = {k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=900 + i, recipe="feedback").items()}
     m.load_state_dict(sd, strict=False)
     m = m.cuda()
-    fc = feats_t(synthetic.synthetic_features(B, seed=1100 + i))
-    fc = {k: (v[:, :S].contiguous() if v.dim() > 1 and v.shape[1] == 300 else v) for k, v in fc.items()}
+    fc = feats_t(synthetic.synthetic_features(B, seed=1100 + i, n_frames=S))
     f = {k: v.cuda() for k, v in fc.items()}
     prim = torch.tensor([C.primer_from_name(n) for n in ["C", "A:min", "D:min"][:P]])
     fails = []
