@@ -22,15 +22,30 @@ __device__ __forceinline__ void route_token(const float* __restrict__ xrow, cons
                                             int d, int n_exp, int lane, int& i0, int& i1, float& w0, float& w1) {
     float best0 = -INFINITY, best1 = -INFINITY;
     i0 = 0; i1 = 0;
-    for (int e = 0; e < n_exp; ++e) {
-        float s = 0.f;
+    // eight experts per pass, their gate rows requested together (unguarded: surplus slots re-read the last expert's row): one expert per
+    // loop iteration was one L2 round trip per expert, which is what a one-token launch of the lockstep decode step pays for.  Every
+    // expert's sum runs over the chunks in the same order as before (bit-identical logits).
+    for (int e0 = 0; e0 < n_exp; e0 += 8) {
+        float s[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = 0.f;
         for (int c = lane * 4; c < d; c += 256) {
-            const float4 a = ld4(xrow + c), w = ld4(gw + (size_t)e * d + c);
-            s += a.x * w.x + a.y * w.y + a.z * w.z + a.w * w.w;
+            const float4 a = ld4(xrow + c);
+            float4 w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = ld4(gw + (size_t)min(e0 + j, n_exp - 1) * d + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += a.x * w[j].x + a.y * w[j].y + a.z * w[j].z + a.w * w[j].w;
         }
-        s = wave_sum(s) + (gb ? gb[e] : 0.f);
-        if (s > best0) { best1 = best0; i1 = i0; best0 = s; i0 = e; }
-        else if (s > best1) { best1 = s; i1 = e; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = e0 + j;
+            if (e < n_exp) {
+                const float sj = wave_sum(s[j]) + (gb ? gb[e] : 0.f);
+                if (sj > best0) { best1 = best0; i1 = i0; best0 = sj; i0 = e; }
+                else if (sj > best1) { best1 = sj; i1 = e; }
+            }
+        }
     }
     const float e1 = __expf(best1 - best0);
     w0 = 1.0f / (1.0f + e1);
