@@ -517,12 +517,18 @@ __global__ __launch_bounds__(64) void v2_decide_fused_kernel(const float* __rest
                                                             const float* __restrict__ keys, const float* __restrict__ PR, const float* __restrict__ PA,
                                                             const float* __restrict__ wkey, const float* __restrict__ bias,
                                                             const float* __restrict__ pe, float* __restrict__ x_next, int d) {
-    __shared__ int s_ra[2];
     const int b = blockIdx.x, lane = threadIdx.x;
     const int cur = state[0] + 1;
     if (cur < T) {
+        // (root, attr) of position cur: decided here (every lane holds the same token after pick_token), or the stored primer's.  They used
+        // to travel lane 0 -> global memory -> lane 0 -> LDS: a store / load round trip and two barriers inside a one-wave kernel.
+        int root, attr;
         if (cur >= n_primer) {
             const float* lg = logits + (size_t)b * ld_logits;
+            // the id history is requested before the logits are reduced (it sat behind the first reduction: one more L2 round trip)
+            const int64_t prev = tokens[(size_t)b * T + cur - 1];
+            bool rep = beam == 0 && cur >= max_conseq_chord;
+            for (int k = 1; rep && k < max_conseq_chord; ++k) rep = tokens[(size_t)b * T + cur - 1 - k] == prev;
             float z[3];
             float m = -INFINITY;
 #pragma unroll
@@ -534,9 +540,6 @@ __global__ __launch_bounds__(64) void v2_decide_fused_kernel(const float* __rest
             m = wave_max(m);
             float pr[3];
             float ps = 0.f;
-            const int64_t prev = tokens[(size_t)b * T + cur - 1];
-            bool rep = beam == 0 && cur >= max_conseq_chord;
-            for (int k = 1; rep && k < max_conseq_chord; ++k) rep = tokens[(size_t)b * T + cur - 1 - k] == prev;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int n = lane + 64 * k;
@@ -549,25 +552,23 @@ __global__ __launch_bounds__(64) void v2_decide_fused_kernel(const float* __rest
             SampleParams sp{};
             sp.beam = beam; sp.uniforms = uniforms; sp.B = B;
             const int tok = pick_token(sp, pr, ps, lane, b, cur - 1);
+            root = ROOT_PAD; attr = ATTR_PAD;
+            if (chord_embed) { root = tok; attr = 0; }
+            else if (beam == 0) { root = tok == 0 ? 0 : (tok - 1) / 13 + 1; attr = tok == 0 ? 1 : (tok - 1) % 13 + 1; }
             if (lane == 0) {
                 tokens[(size_t)b * T + cur] = tok;
-                int root = ROOT_PAD, attr = ATTR_PAD;
-                if (chord_embed) { root = tok; attr = 0; }
-                else if (beam == 0) { root = tok == 0 ? 0 : (tok - 1) / 13 + 1; attr = tok == 0 ? 1 : (tok - 1) % 13 + 1; }
                 roots[(size_t)b * T + cur] = root;
                 attrs[(size_t)b * T + cur] = attr;
             }
+        } else {
+            root = (int)roots[(size_t)b * T + cur];
+            attr = (int)attrs[(size_t)b * T + cur];
         }
-        __syncthreads();
         if (lane == 0) {
-            s_ra[0] = (int)roots[(size_t)b * T + cur];
-            s_ra[1] = (int)attrs[(size_t)b * T + cur];
-            state[1 + b] = s_ra[0];
-            state[1 + B + b] = s_ra[1];
+            state[1 + b] = root;
+            state[1 + B + b] = attr;
         }
-        __syncthreads();
         // x_next[b] = chord-stream row of position cur (the summation order of embed_rows_kernel)
-        const int root = s_ra[0], attr = s_ra[1];
         const float kv = keys[b];
         const float* pp_row = pe ? pe + (size_t)cur * d : nullptr;
         for (int c = lane * 4; c < d; c += 256) {
