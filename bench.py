@@ -303,6 +303,11 @@ def roofline(model, f, prim, B, T, cfg):
     n_gemm = st["decode_gemm"]["launches"] / steps
     sample_us = max(raw_us("sample") - empty_us, 0.0)
     gemm_in_chain_us = (step_us - nl * (self_us + cross_us) - sample_us) / max(n_gemm, 1)
+    if gemm_in_chain_us <= 0.05:                 # a difference of timings: at small shapes it can come out at or below zero
+        gemm_in_chain_us = None
+
+    def rate(nbytes, us):
+        return (None, None) if not us else (round(nbytes / us / 1e3, 1), round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4))
     shape_ok = B == 32 and d == 512 and cfg["num_heads"] == 8
     traffic, traffic_src = pmc_traffic("self_attn", self_bytes, shape_ok)
     return {
@@ -320,8 +325,9 @@ def roofline(model, f, prim, B, T, cfg):
                        "achieved": round(cross_bytes / cross_us / 1e3, 1), "frac": round(cross_bytes / cross_us / 1e3 / HBM_PEAK_GBS, 4),
                        "traffic": pmc_traffic("cross_attn", cross_bytes, shape_ok)[0], "event_pair": ev("cross_attn_decode", cross_bytes)},
         "decode_gemm": {"kernel": "decode_gemm_kernel<4,true,0> (G1, G2) and <6,true,2> (G3): weight-streaming skinny GEMMs, 18 launches per step",
-                        "packed_weight_bytes_per_launch": round(gemm_bytes), "avg_launch_us": round(gemm_in_chain_us, 3),
-                        "achieved": round(gemm_bytes / gemm_in_chain_us / 1e3, 1), "frac": round(gemm_bytes / gemm_in_chain_us / 1e3 / HBM_PEAK_GBS, 4),
+                        "packed_weight_bytes_per_launch": round(gemm_bytes),
+                        "avg_launch_us": None if gemm_in_chain_us is None else round(gemm_in_chain_us, 3),
+                        "achieved": rate(gemm_bytes, gemm_in_chain_us)[0], "frac": rate(gemm_bytes, gemm_in_chain_us)[1],
                         "measured": "in the chain: (step us - attention launches - sampling head) / GEMM launches; latency-bound "
                                     "(profiles/r02_skinny_gemm_timeline_before.txt, r02_pmc_decode_step_SQ.json: 86 % of wave cycles waiting)",
                         "event_pair": ev("decode_gemm", gemm_bytes)},

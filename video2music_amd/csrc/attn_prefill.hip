@@ -313,6 +313,10 @@ __global__ __launch_bounds__(256) void attn_prefill_splitk_kernel(AttnParams p) 
             st4(&Ks[r * LD + c], kst[i]);
             st4(&Vs[r * LD + c], vst[i]);
         }
+        // the tile is staged by this wave for this wave alone: LDS operations of one wave execute in order, so no s_barrier is
+        // needed -- but other LANES read these words below, which the compiler must not reorder around the stores
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         if (kt + 4 < n_tiles) gload(j0 + 4 * KT);
         f32x16 sacc;
 #pragma unroll
@@ -357,6 +361,9 @@ __global__ __launch_bounds__(256) void attn_prefill_splitk_kernel(AttnParams p) 
                 oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, sacc[e], oacc[dt], 0, 0, 0);
             }
         }
+        // (and the next tile's stores stay behind this tile's fragment reads)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
     // ---- merge the 4 waves' states: partial O (un-normalised, [query][d]) | m | l in the wave's own LDS region ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

@@ -587,7 +587,9 @@ __global__ __launch_bounds__(64) void v2_decide_fused_kernel(const float* __rest
         const int ticket = atomicAdd(&state[1 + 2 * B], 1);
         if (ticket == B - 1) {
             state[1 + 2 * B] = 0;
-            state[0] = cur;
+            // never past the last position: a replay too many then recomputes position T-1 (cache row T-1 exists, T <= cap is the
+            // caller's contract) instead of walking the K/V caches out of bounds
+            state[0] = min(cur, T - 1);
         }
     }
 }

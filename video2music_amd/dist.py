@@ -49,7 +49,8 @@ def all_gather_sequences(tokens, n_clips=None):
 
     Shard sizes are never exchanged: with ``n_clips`` given they follow from ``shard_bounds`` on every
     rank (ragged shards are padded to the largest one for the collective and trimmed afterwards);
-    without it every rank must hold the same number of clips (the bench's case)."""
+    without it every rank MUST hold the same number of clips (the bench's case: a precondition, not checked by an
+    exchange; with ``AMT_DIST_CHECK=1`` the shard sizes are compared with one small all-reduce first)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return tokens
     if tokens.is_cuda and dist.get_backend() == "gloo":      # rehearsal path: gloo gathers host tensors
@@ -57,9 +58,15 @@ def all_gather_sequences(tokens, n_clips=None):
     world, rank = dist.get_world_size(), dist.get_rank()
     if n_clips is None:
         sizes = [tokens.shape[0]] * world
+        if os.environ.get("AMT_DIST_CHECK", "0") == "1":       # debug aid: unequal shards would hang or corrupt the collective
+            n = torch.tensor([tokens.shape[0], -tokens.shape[0]], dtype=torch.int64, device=tokens.device)
+            dist.all_reduce(n, op=dist.ReduceOp.MAX)
+            if int(n[0]) != -int(n[1]):
+                raise ValueError(f"all_gather_sequences without n_clips: shards of {-int(n[1])}..{int(n[0])} clips; pass n_clips")
     else:
         sizes = [hi - lo for lo, hi in (shard_bounds(n_clips, r, world) for r in range(world))]
-        assert tokens.shape[0] == sizes[rank], f"rank {rank} holds {tokens.shape[0]} clips, shard_bounds says {sizes[rank]}"
+        if tokens.shape[0] != sizes[rank]:
+            raise ValueError(f"rank {rank} holds {tokens.shape[0]} clips, shard_bounds says {sizes[rank]}")
     mx = max(sizes)
     pad = tokens
     if tokens.shape[0] < mx:

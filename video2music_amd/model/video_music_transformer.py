@@ -845,26 +845,33 @@ class VideoMusicTransformer_V2(nn.Module):
                 keep.append(t)
                 ptrs.append(t.data_ptr())
 
+        cache = self.__dict__.setdefault("_pack_cache", {})
+
+        def cached(ident, version, build):
+            """One entry per identity (storage pointers + role); a new parameter version (load_state_dict, an optimiser step
+            followed by eval) REPLACES the entry, so stale packed copies do not stay resident."""
+            hit = cache.get(ident)
+            if hit is None or hit[0] != version:
+                cache[ident] = hit = (version, build())
+            return hit[1]
+
+        def pack_now(w, rows=None):
+            src = (w if rows is None else w[:rows]).detach().contiguous()
+            N, K = src.shape
+            out = torch.empty((N + 15) // 16 * 16 * K, device=dev, dtype=torch.float32)
+            _lib.call("amt_pack_weight_fwd", _lib.ptr(src), _lib.ptr(out), N, K, _lib.stream_ptr())
+            return out
+
         def packed(w, rows=None):
             """Weight (N, K) [or its first `rows` rows] in the skinny GEMM's tile order; packed once per parameter version."""
             w = w.detach()
-            sig = (w.data_ptr(), w._version, rows)
-            cache = self.__dict__.setdefault("_pack_cache", {})
-            if sig not in cache:
-                src = (w if rows is None else w[:rows]).contiguous()
-                N, K = src.shape
-                out = torch.empty((N + 15) // 16 * 16 * K, device=dev, dtype=torch.float32)
-                _lib.call("amt_pack_weight_fwd", _lib.ptr(src), _lib.ptr(out), N, K, _lib.stream_ptr())
-                cache[sig] = out
-            return cache[sig]
+            return cached((w.data_ptr(), rows), w._version, lambda: pack_now(w, rows))
 
         def packed_experts(experts, name):
+            # (the per-expert packed pieces are temporaries: only the concatenation stays resident)
             lins = [expert_parts(e)[name] for e in experts]
-            sig = tuple((l.weight.data_ptr(), l.weight._version) for l in lins) + (name,)
-            cache = self.__dict__.setdefault("_pack_cache", {})
-            if sig not in cache:
-                cache[sig] = torch.cat([packed(l.weight) for l in lins])
-            return cache[sig]
+            return cached(tuple(l.weight.data_ptr() for l in lins) + (name,), tuple(l.weight._version for l in lins),
+                          lambda: torch.cat([pack_now(l.weight) for l in lins]))
 
         def nbias(n):       # a norm's bias; None (RMSNorm) selects the RMS form inside the step
             return getattr(n, "bias", None)
@@ -901,18 +908,19 @@ class VideoMusicTransformer_V2(nn.Module):
                 gate/up product), and, for a mixture layer, linear2 of every module one after the other + biases."""
                 parts = [expert_parts(e) for e in mods]
                 srcs = [q[n] for n in ("gate", "linear1", "linear2") for q in parts if q[n] is not None]
-                sig = tuple((l.weight.data_ptr(), l.weight._version, l.bias.data_ptr(), l.bias._version) for l in srcs) + ("stacked", with_down)
-                cache = self.__dict__.setdefault("_pack_cache", {})
-                if sig not in cache:
+
+                def build():
                     gu = [q["gate"] for q in parts] + [q["linear1"] for q in parts if q["linear1"] is not None]
-                    out = [torch.cat([packed(l.weight) for l in gu]), torch.cat([l.bias.detach() for l in gu]).contiguous()]
+                    out = [torch.cat([pack_now(l.weight) for l in gu]), torch.cat([l.bias.detach() for l in gu]).contiguous()]
                     if with_down:
-                        out += [torch.cat([packed(q["linear2"].weight) for q in parts]),
+                        out += [torch.cat([pack_now(q["linear2"].weight) for q in parts]),
                                 torch.cat([q["linear2"].bias.detach() for q in parts]).contiguous()]
                     else:
                         out += [None, None]
-                    cache[sig] = out
-                return cache[sig]
+                    return out
+
+                return cached(tuple((l.weight.data_ptr(), l.bias.data_ptr()) for l in srcs) + ("stacked", with_down),
+                              tuple((l.weight._version, l.bias._version) for l in srcs), build)
 
             if isinstance(ff, (GLUExpert, SiLUExpert)):
                 layer_dff = expert_dff(ff)
@@ -925,6 +933,10 @@ class VideoMusicTransformer_V2(nn.Module):
             else:
                 if ff.n_experts_per_token != 2 or getattr(ff, "expert_parallel", False):
                     raise NotImplementedError("the cached V2 step is built for local top-2 MoE layers")
+                if hasattr(ff, "temperature_scheduler"):
+                    # the scheduler steps in every forward (moe.py:238-240) and rescales the routing logits; the cached step hands
+                    # the raw gate to the device, so such a layer must take the per-step re-forward
+                    raise NotImplementedError("the cached V2 step does not evaluate a SharedMoELayer temperature_scheduler")
                 layer_dff = expert_dff(ff.experts[0])
                 add(ff.gate.weight), add(ff.gate.bias)
                 for name in ("linear1", "gate", "linear2"):
@@ -947,17 +959,17 @@ class VideoMusicTransformer_V2(nn.Module):
             if isinstance(lyr.norm1, nn.LayerNorm) and 2 * E <= 1536 and os.environ.get("AMT_V2_FOLD_G1", "1") != "0":
                 from .. import ops
                 srcs = (sa.out_proj.weight, sa.out_proj.bias, ca.in_proj_weight, ca.in_proj_bias, lyr.norm1.weight, lyr.norm1.bias)
-                sig = tuple((t.data_ptr(), t._version) for t in srcs) + ("g1fold",)
-                cache = self.__dict__.setdefault("_pack_cache", {})
-                if sig not in cache:
+
+                def build_fold(sa=sa, ca=ca, lyr=lyr):
                     Wo, bo, Wq, bq = sa.out_proj.weight.detach(), sa.out_proj.bias.detach(), ca.in_proj_weight.detach()[:E], ca.in_proj_bias.detach()[:E]
                     gamma, beta = lyr.norm1.weight.detach(), lyr.norm1.bias.detach()
                     Wqg = (Wq * gamma.unsqueeze(0)).contiguous()                              # Wq o gamma
                     A = ops.linear(Wqg, Wo.t().contiguous())                                   # (Wq o gamma) Wo
-                    P2 = torch.cat([A, Wqg], dim=1).contiguous()                               # (E, 2E)
-                    cache[sig] = [packed(P2), ops.linear(bo.view(1, E).contiguous(), Wqg).view(E).contiguous(),
-                                  Wqg.sum(dim=1).contiguous(), (ops.linear(beta.view(1, E).contiguous(), Wq.contiguous()).view(E) + bq).contiguous(), P2]
-                for t in cache[sig][:4]:
+                    P2 = torch.cat([A, Wqg], dim=1).contiguous()                               # (E, 2E), a temporary
+                    return [pack_now(P2), ops.linear(bo.view(1, E).contiguous(), Wqg).view(E).contiguous(),
+                            Wqg.sum(dim=1).contiguous(), (ops.linear(beta.view(1, E).contiguous(), Wq.contiguous()).view(E) + bq).contiguous()]
+
+                for t in cached(tuple(t.data_ptr() for t in srcs) + ("g1fold",), tuple(t._version for t in srcs), build_fold):
                     add(t)
             else:
                 for _ in range(4):
@@ -1199,6 +1211,8 @@ class VideoMusicTransformer_V2(nn.Module):
             else:
                 for _ in range(T - 2):
                     step(False)
+        # the captured graphs, `state`, `unif` and the id tables go out of scope with up to T-2 replays still queued: finish them here
+        torch.cuda.current_stream().synchronize()
         return tokens
 
     def _lockstep_loop(self, next_logits, gen, gen_root, gen_attr, ra_table, nb, T, P, beam, max_conseq_N, max_conseq_chord,
