@@ -234,6 +234,15 @@ int32_t amt_gqa_fwd(const float* query, const float* key, const float* value,
                     const float* ln_w, const float* ln_b, const float* wo, const float* bo,
                     float* out, float* scratch, int32_t L, int32_t S, int32_t B, int32_t E, int32_t query_heads,
                     int32_t kv_heads, int32_t is_causal, float ln_eps, void* stream);
+/* The same with MultiheadGQA(RoPE=...) (grouped_query_attention.py:316-322): the projected q and k are rotated through the raw
+ * (heads, len, B, head_dim) view with the module's cos/sin cache (cache_rows, cache_half, 2) -- cache_half = dim/2 of the
+ * RotaryPositionalEmbeddings the caller built, head_dim/2 or a multiple that the view folds (rotate_operation.py:148-149). */
+int32_t amt_gqa_rope_fwd(const float* query, const float* key, const float* value,
+                         const float* wq, const float* bq, const float* wk, const float* bk, const float* wv, const float* bv,
+                         const float* ln_w, const float* ln_b, const float* wo, const float* bo,
+                         float* out, float* scratch, int32_t L, int32_t S, int32_t B, int32_t E, int32_t query_heads,
+                         int32_t kv_heads, int32_t is_causal, float ln_eps, const float* rope_cache, int32_t cache_rows,
+                         int32_t cache_half, void* stream);
 /* MoELayer.forward / SharedMoELayer.forward, eval mode (moe.py:167-200,231-302): x (n_tok,d);
  * gate (n_exp,d)+(n_exp); experts' linear1/gate (n_exp,dff,d)+(n_exp,dff), linear2 (n_exp,d,dff)+(n_exp,d);
  * shared_* may be null.  top-k = 2.  idx_out/w_out (optional) receive the routing (n_tok,2).

@@ -393,7 +393,7 @@ def rope(x, cache, input_pos=None):
     return out.flatten(3).type_as(x)
 
 
-def gqa_forward(query, key, value, sd, query_heads, kv_heads, is_causal=False, layer_norm_eps=1e-5):
+def gqa_forward(query, key, value, sd, query_heads, kv_heads, is_causal=False, layer_norm_eps=1e-5, rope_cache_=None):
     """model/grouped_query_attention.py:286-358 (MultiheadGQA.forward) + :19-170, Appendix A5.
 
     Inputs are seq-first ``(L,B,E)`` like the reference's callers pass; the reference then
@@ -406,10 +406,14 @@ def gqa_forward(query, key, value, sd, query_heads, kv_heads, is_causal=False, l
     v = linear(value, sd["v_proj.weight"], sd["v_proj.bias"])
     hd = E // query_heads
     g = query_heads // kv_heads
+    src_len = k.shape[0]
+    if rope_cache_ is not None:          # RoPE=... (:316-322): rotation through the raw (heads, len, B, hd) view
+        q = rope(q.contiguous().view(query_heads, L, B, hd), rope_cache_)
+        k = rope(k.contiguous().view(kv_heads, src_len, B, hd), rope_cache_)
     # raw memory reinterpretation (L,B,*) -> (B,L,heads,hd)
     q = q.contiguous().view(B, L, query_heads, hd)
-    k = k.contiguous().view(B, k.shape[0], kv_heads, hd)
-    v = v.contiguous().view(B, v.shape[0], kv_heads, hd)
+    k = k.contiguous().view(B, src_len, kv_heads, hd)
+    v = v.contiguous().view(B, src_len, kv_heads, hd)
     q = q.permute(0, 2, 1, 3) / (hd ** 0.5)                    # b (h g) n d, scale :121-123
     k = k.permute(0, 2, 1, 3)
     v = v.permute(0, 2, 1, 3)

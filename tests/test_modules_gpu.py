@@ -35,6 +35,26 @@ def test_gqa_vs_reference_golden(golden, L, B, causal):
     assert err < 1e-4, err
 
 
+@pytest.mark.parametrize("name,dim", [("hd", 32), ("full", 256)])
+def test_gqa_rope_vs_reference_golden(golden, name, dim):
+    """MultiheadGQA(RoPE=RotaryPositionalEmbeddings(dim, 80)) (grouped_query_attention.py:216,316-322): the rotation through the raw
+    (heads, len, B, head_dim) view, cache built for head_dim (broadcast) and for embed_dim (folded and truncated), B in {1,2,3}."""
+    g = golden("g_gqa_rope.npz")
+    m, _ = load(MultiheadGQA(256, 8, 2, RoPE=RotaryPositionalEmbeddings(dim, 80)), GQA_SHAPES, 3)
+    for L, B in ((6, 1), (6, 2), (64, 1), (64, 3)):
+        x = torch.from_numpy(g[f"{name}_x_L{L}_B{B}"]).cuda()
+        for causal in (False, True):
+            y, _ = m(x, x, x, is_causal=causal)
+            err = np.abs(y.cpu().numpy() - g[f"{name}_y_L{L}_B{B}_c{int(causal)}"]).max()
+            assert err < 1e-4, (L, B, causal, err)
+    xq, xk = torch.from_numpy(g[f"{name}_xq"]).cuda(), torch.from_numpy(g[f"{name}_xk"]).cuda()
+    y, _ = m(xq, xk, xk)
+    assert np.abs(y.cpu().numpy() - g[f"{name}_y_cross"]).max() < 1e-4
+    with pytest.raises(ValueError):                    # longer than the cache
+        x = torch.zeros(81, 1, 256, device="cuda")
+        m(x, x, x)
+
+
 def test_gqa_config4_vs_oracle():
     """Config 4: MultiheadGQA(512, 8, 2), is_causal, L=2048 (B=1) and the B=4 row-permutation quirk at L=512."""
     shapes = [("q_proj.weight", (512, 512)), ("q_proj.bias", (512,)), ("k_proj.weight", (128, 512)), ("k_proj.bias", (128,)),

@@ -94,6 +94,22 @@ def test_gqa(golden, L, B, causal):
     assert np.abs(y.numpy() - g[f"y_L{L}_B{B}_c{int(causal)}"]).max() < TOL
 
 
+@pytest.mark.parametrize("name,dim", [("hd", 32), ("full", 256)])
+def test_gqa_rope(golden, name, dim):
+    """MultiheadGQA(RoPE=...) of the reference (grouped_query_attention.py:316-322): cache built for head_dim and for embed_dim."""
+    g = golden("g_gqa_rope.npz")
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(GQA_SHAPES, seed=3).items()}
+    cache = O.rope_cache(dim, 80)
+    for L, B in ((6, 1), (6, 2), (64, 1), (64, 3)):
+        x = torch.from_numpy(g[f"{name}_x_L{L}_B{B}"])
+        for causal in (False, True):
+            y = O.gqa_forward(x, x, x, sd, 8, 2, is_causal=causal, rope_cache_=cache)
+            assert np.abs(y.numpy() - g[f"{name}_y_L{L}_B{B}_c{int(causal)}"]).max() < TOL, (L, B, causal)
+    xq, xk = torch.from_numpy(g[f"{name}_xq"]), torch.from_numpy(g[f"{name}_xk"])
+    y = O.gqa_forward(xq, xk, xk, sd, 8, 2, rope_cache_=cache)
+    assert np.abs(y.numpy() - g[f"{name}_y_cross"]).max() < TOL
+
+
 def moe_shapes(n_exp, d, dff, shared):
     out = [("gate.weight", (n_exp, d)), ("gate.bias", (n_exp,))]
     names = [f"experts.{e}." for e in range(n_exp)] + (["shared_expert."] if shared else [])

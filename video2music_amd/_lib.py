@@ -70,6 +70,7 @@ SIGNATURES = {
     "amt_attn_decode_fold_fwd": [_P, _I] + [_P] * 10 + [_I, _I, _I, _I, _P, _I, _I, _I, _F, _F, _P],
     "amt_decode_gemm_ex_fwd": [_P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P],
     "amt_gqa_fwd": [_P] * 15 + [_I] * 7 + [_F, _P],
+    "amt_gqa_rope_fwd": [_P] * 15 + [_I] * 7 + [_F, _P, _I, _I, _P],
     "amt_moe_scratch_floats": [_I, _I, _I, _I],
     "amt_moe_fwd": [_P] * 19 + [_I] * 4 + [_P],
     "amt_moe_topk_scratch_floats": [_I, _I, _I, _I, _I],

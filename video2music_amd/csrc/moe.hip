@@ -416,11 +416,11 @@ extern "C" int32_t amt_moe_combine_fwd(const float* y_rows, const int32_t* slot_
     return 0;
 }
 
-extern "C" int32_t amt_gqa_fwd(const float* query, const float* key, const float* value,
-                               const float* wq, const float* bq, const float* wk, const float* bk, const float* wv, const float* bv,
-                               const float* ln_w, const float* ln_b, const float* wo, const float* bo,
-                               float* out, float* scratch, int32_t L, int32_t S, int32_t B, int32_t E, int32_t query_heads,
-                               int32_t kv_heads, int32_t is_causal, float ln_eps, void* stream) {
+static int32_t gqa_impl(const float* query, const float* key, const float* value,
+                        const float* wq, const float* bq, const float* wk, const float* bk, const float* wv, const float* bv,
+                        const float* ln_w, const float* ln_b, const float* wo, const float* bo,
+                        float* out, float* scratch, int32_t L, int32_t S, int32_t B, int32_t E, int32_t query_heads,
+                        int32_t kv_heads, int32_t is_causal, float ln_eps, const float* rope_cache, int32_t cache_half, void* stream) {
     AMT_CHECK_ARG(query && key && value && wq && wk && wv && wo && out && scratch, "amt_gqa_fwd: null pointer");
     AMT_CHECK_ARG(query_heads > 0 && kv_heads > 0 && query_heads % kv_heads == 0 && E % query_heads == 0, "amt_gqa_fwd: bad head counts");
     hipStream_t s = (hipStream_t)stream;
@@ -435,6 +435,13 @@ extern "C" int32_t amt_gqa_fwd(const float* query, const float* key, const float
     if ((rc = amt_launch_gemm(gq, s))) return rc;
     if ((rc = amt_launch_gemm(gemm_params(key, E, wk, E, k, Ekv, S * B, Ekv, E, bk), s))) return rc;
     if ((rc = amt_launch_gemm(gemm_params(value, E, wv, E, v, Ekv, S * B, Ekv, E, bv), s))) return rc;
+    if (rope_cache) {
+        // RoPE on the raw (heads, len, B, hd) view of the projection buffers (:316-322), in place.  The reference rotates before
+        // it divides the query by sqrt(hd) (:121-123); the rotation is linear, so the scaled query rotates to the same values up
+        // to fp32 rounding
+        if ((rc = amt_launch_rope(q, rope_cache, q, query_heads, L, B, hd, cache_half, s))) return rc;
+        if ((rc = amt_launch_rope(k, rope_cache, k, kv_heads, S, B, hd, cache_half, s))) return rc;
+    }
     // the reference reinterprets the (L,B,.) projection buffers in memory order as (B,L,.) (:316-326):
     // batch-first strides on the same memory; the output is written transposed back as (L',B',E) (:159)
     AttnParams p{};
@@ -449,4 +456,25 @@ extern "C" int32_t amt_gqa_fwd(const float* query, const float* key, const float
         if ((rc = amt_launch_layernorm(a, nullptr, ln_w, ln_b, nullptr, nullptr, a, L * B, E, ln_eps, s))) return rc;
     }
     return amt_launch_gemm(gemm_params(proj_in, E, wo, E, out, E, L * B, E, E, bo), s);
+}
+
+extern "C" int32_t amt_gqa_fwd(const float* query, const float* key, const float* value,
+                               const float* wq, const float* bq, const float* wk, const float* bk, const float* wv, const float* bv,
+                               const float* ln_w, const float* ln_b, const float* wo, const float* bo,
+                               float* out, float* scratch, int32_t L, int32_t S, int32_t B, int32_t E, int32_t query_heads,
+                               int32_t kv_heads, int32_t is_causal, float ln_eps, void* stream) {
+    return gqa_impl(query, key, value, wq, bq, wk, bk, wv, bv, ln_w, ln_b, wo, bo, out, scratch, L, S, B, E, query_heads, kv_heads, is_causal,
+                    ln_eps, nullptr, 0, stream);
+}
+
+extern "C" int32_t amt_gqa_rope_fwd(const float* query, const float* key, const float* value,
+                                    const float* wq, const float* bq, const float* wk, const float* bk, const float* wv, const float* bv,
+                                    const float* ln_w, const float* ln_b, const float* wo, const float* bo,
+                                    float* out, float* scratch, int32_t L, int32_t S, int32_t B, int32_t E, int32_t query_heads,
+                                    int32_t kv_heads, int32_t is_causal, float ln_eps, const float* rope_cache, int32_t cache_rows,
+                                    int32_t cache_half, void* stream) {
+    AMT_CHECK_ARG(rope_cache && cache_half > 0 && cache_rows >= L && cache_rows >= S, "amt_gqa_rope_fwd: the rope cache has %d rows, the sequences %d / %d",
+                  cache_rows, L, S);
+    return gqa_impl(query, key, value, wq, bq, wk, bk, wv, bv, ln_w, ln_b, wo, bo, out, scratch, L, S, B, E, query_heads, kv_heads, is_causal,
+                    ln_eps, rope_cache, cache_half, stream);
 }

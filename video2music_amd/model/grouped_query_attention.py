@@ -3,9 +3,13 @@
 Same constructor, parameter names (q_proj/k_proj/v_proj/norm/out_proj) and ``forward`` signature.
 Inputs are the caller's ``(L, B, E)`` buffers; like the reference, the projected q/k/v memory is
 reinterpreted as ``(B, L, ·)`` (:316-326), which mixes clips when B > 1 — reproduced exactly.
-``attn_mask`` is accepted and ignored like in the reference (:339); ``need_weights``, RoPE and
-``key_padding_mask`` are not on the hot path and raise.
+``attn_mask`` is accepted and ignored like in the reference (:339).  ``RoPE=`` (a ``RotaryPositionalEmbeddings``, deep-copied like
+in the reference, :216) rotates the projected q / k through the raw ``(heads, len, B, head_dim)`` view (:316-322) inside
+``amt_gqa_rope_fwd``.  ``need_weights`` and ``key_padding_mask`` are not on the hot path and raise; ``dropout > 0`` raises too:
+the reference applies ``F.dropout`` to the attention map even in eval (:152-153), i.e. a random result.
 """
+import copy
+
 import torch
 import torch.nn as nn
 
@@ -23,10 +27,11 @@ class MultiheadGQA(nn.Module):
         head_dim = embed_dim // query_heads
         if head_dim % 8 != 0 or head_dim > 128:
             raise ValueError(f"head_dim {head_dim} must be divisible by 8 and <= 128")
-        if RoPE is not None or dropout > 0.0:
-            raise NotImplementedError("RoPE / attention dropout inside MultiheadGQA are outside the hot path")
+        if dropout > 0.0:
+            raise NotImplementedError("attention dropout inside MultiheadGQA (random even in eval, :152-153) is outside the hot path")
         self.query_heads, self.kv_heads, self.dropout = query_heads, kv_heads, dropout
-        self.layer_norm, self.gamma_init, self.embed_dim, self.RoPE = layer_norm, gamma_init, embed_dim, None
+        self.layer_norm, self.gamma_init, self.embed_dim = layer_norm, gamma_init, embed_dim
+        self.RoPE = copy.deepcopy(RoPE)         # :216
         kv_embed_dim = head_dim * kv_heads
         self.q_proj = nn.Linear(embed_dim, embed_dim, bias=bias, device=device, dtype=dtype)
         self.k_proj = nn.Linear(embed_dim, kv_embed_dim, bias=bias, device=device, dtype=dtype)
@@ -67,7 +72,17 @@ class MultiheadGQA(nn.Module):
         (wq, bq), (wk, bk), (wv, bv), (wo, bo) = w(self.q_proj), w(self.k_proj), w(self.v_proj), w(self.out_proj)
         lnw = p(self.norm.weight.detach()) if self.norm is not None else None
         lnb = p(self.norm.bias.detach()) if self.norm is not None else None
-        _lib.call("amt_gqa_fwd", p(q), p(k), p(v), wq, bq, wk, bk, wv, bv, lnw, lnb, wo, bo, p(out), p(scratch),
-                  L, S, B, E, self.query_heads, self.kv_heads, int(bool(is_causal)),
-                  float(self.norm.eps) if self.norm is not None else 1e-5, _lib.stream_ptr())
+        eps = float(self.norm.eps) if self.norm is not None else 1e-5
+        if self.RoPE is None:
+            _lib.call("amt_gqa_fwd", p(q), p(k), p(v), wq, bq, wk, bk, wv, bv, lnw, lnb, wo, bo, p(out), p(scratch),
+                      L, S, B, E, self.query_heads, self.kv_heads, int(bool(is_causal)), eps, _lib.stream_ptr())
+        else:
+            cache = self.RoPE.cache
+            if cache.device != q.device or not cache.is_contiguous():
+                cache = cache.to(q.device).contiguous()
+            if max(L, S) > cache.shape[0]:
+                raise ValueError(f"sequence length {max(L, S)} exceeds the rope cache ({cache.shape[0]})")
+            _lib.call("amt_gqa_rope_fwd", p(q), p(k), p(v), wq, bq, wk, bk, wv, bv, lnw, lnb, wo, bo, p(out), p(scratch),
+                      L, S, B, E, self.query_heads, self.kv_heads, int(bool(is_causal)), eps, p(cache), cache.shape[0], cache.shape[1],
+                      _lib.stream_ptr())
         return out, None
