@@ -23,11 +23,20 @@
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
  *     nothing synchronises the device except amt_finalize / amt_destroy.  amt_generate captures
  *     its decode step into a hipGraph on first use for a given (batch, mode).
- *   - one handle per (process, device); a handle is not thread-safe.
+ *   - threading: one handle per (process, device); a handle and everything it owns (workspaces, K/V caches, captured graphs,
+ *     options) belongs to ONE host thread at a time.  The stateless operator entry points may be called from several host
+ *     threads concurrently, each on its own stream, as long as they share no output or scratch buffer.
+ *   - global state: the library keeps no mutable global besides (a) the thread-local error message, (b) per-device one-time
+ *     initialisations (the > 64 KiB dynamic-LDS opt-in of a kernel, a 256-byte block of zero words), each taken under a mutex,
+ *     and (c) the immutable tuning record of csrc/amt_common.h.  The release build reads NO environment variable; a
+ *     -DAMT_EXPERIMENT build (tools/ab_build.sh) reads the A/B switches of DESIGN.md once, under std::call_once.
+ *   - amt_abi_version() == AMT_ABI_VERSION of the header the caller was built against, or the caller must refuse the library.
  */
 #ifndef AMT_HIP_H
 #define AMT_HIP_H
 #include <stdint.h>
+
+#define AMT_ABI_VERSION 2    /* 2: argument structs for the step / skinny-GEMM calls, options in place of amt_debug_set_skip */
 
 #ifdef __cplusplus
 extern "C" {
@@ -108,7 +117,12 @@ int32_t amt_generate_run(amt_handle* h, int32_t n_steps, float* logits_out, void
  *   an all-zero (16, d) "embedding_attr.weight", passes chord ids as the root ids and zeros as the attr ids; the generated id then
  *   feeds back as the root index in both decision branches. */
 /*   "causal_mask" = 0 (any time): amt_prefill runs the decoder self-attention without the subsequent mask (reference
- *   forward(mask=False), :978-982); 1 restores the default. */
+ *   forward(mask=False), :978-982); 1 restores the default.
+ *   "decode_chain_plain" = 1 (before the first amt_finalize): the decode step without folded LayerNorms (49 launches instead of
+ *   31: model/rpr.py:59-69 operator by operator) -- the chain that shapes outside the fold's range take anyway.
+ *   "profile_skip" = 1 | 2 | 3 (any time; results become meaningless): measurement hook of bench.py, leaves the self-attention
+ *   (bit 0) and / or cross-attention (bit 1) launches out of the captured decode step, so that what a kernel costs the step is
+ *   the difference between two timed generates.  0 restores the real step. */
 int32_t amt_set_option(amt_handle* h, const char* name, int32_t value);
 /* amt_encode with rows [B*S][d] added to Linear_vis's output before the encoder: reference scene_embed=True
  * (:1016-1027: the scene offset is left out of the feature columns and scene_embedding(offset.int()) is added instead).  The
@@ -136,10 +150,6 @@ int32_t amt_generate(amt_handle* h, int32_t B, const int64_t* primer, const int6
                      const int64_t* primer_attr, int32_t P, int32_t primer_per_clip, const float* key,
                      int32_t T, int32_t beam, int32_t max_conseq_N, int32_t max_conseq_chord,
                      int64_t* tokens_out, float* logits_out, void* stream);
-/* Measurement aid for bench.py (results become meaningless): leaves the self-attention (bit 0) and/or
- * cross-attention (bit 1) launches out of the decode step, so that the in-situ cost of a kernel is
- * the difference between two timed generates.  0 restores the real step. */
-int32_t amt_debug_set_skip(amt_handle* h, int32_t mask);
 /* Timing/roofline introspection for bench.py: algorithmic HBM bytes of the decode-attention
  * launches of one step at key count n_keys (self) — see DESIGN.md. */
 int64_t amt_decode_step_bytes(const amt_handle* h, int32_t B, int32_t n_self_keys, int32_t S);
@@ -221,12 +231,20 @@ int32_t amt_attn_decode_fold_fwd(const float* raw, int32_t ldq, float* kcache, f
                                  const float* ln_b, float* xn_out, float* o, int32_t B, int32_t H, int32_t hd,
                                  int32_t cap, const int32_t* pos_dev, int32_t n_keys, int32_t er_len, int32_t new_kv,
                                  float eps, float q_scale, void* stream);
-int32_t amt_decode_gemm_ex_fwd(const float* x, int32_t ldx, const float* x2, int32_t ldx2, int32_t K1, int32_t K,
-                               const float* w_low, const float* bias_low, const float* resid, int32_t relu,
-                               const float* w_high, const float* bias_high, int32_t n_low, int32_t n_high,
-                               int32_t pro, const float* fold_g, const float* fold_c, const float* ln_w, const float* ln_b,
-                               float* y_low, float* y_high, float* scratch_low, float* scratch_high,
-                               int32_t B, float eps, void* stream);
+typedef struct amt_decode_gemm_args {
+    const float* x;  int32_t ldx;          /* first K1 columns of the rows (all K when x2 is null) */
+    const float* x2; int32_t ldx2;         /* remaining K - K1 columns, or null */
+    int32_t K1, K;
+    const float* w_low;  const float* bias_low;  const float* resid; int32_t relu;   /* y_low = act(x . w_low^T + b (+ resid)) */
+    const float* w_high; const float* bias_high;                                     /* y_high = [x | x2] . w_high^T + b_high */
+    int32_t n_low, n_high;
+    int32_t pro;                           /* 1: folded-FFN prologue (see above) */
+    const float* fold_g; const float* fold_c; const float* ln_w; const float* ln_b;
+    float* y_low; float* y_high;
+    float* scratch_low; float* scratch_high;   /* packed copies of the weights, ceil(n/16)*16*K floats each */
+    int32_t B; float eps;
+} amt_decode_gemm_args;
+int32_t amt_decode_gemm_ex_fwd(const amt_decode_gemm_args* a, void* stream);
 /* MultiheadGQA.forward (grouped_query_attention.py:286-358) without RoPE: query/key/value are the
  * caller's (L,B,E) buffers, weights in nn.Linear layout; scratch >= 4*L*B*E floats. */
 int32_t amt_gqa_fwd(const float* query, const float* key, const float* value,
@@ -338,11 +356,21 @@ int32_t amt_v2_decide_batch(const float* logits, int32_t ld_logits, int32_t* sta
  * computed from state_dev) and advances state_dev[0].  state_dev: 2 + 2B int32 {position, root[B], attr[B], ticket = 0}.
  * Inside the chain: a mixture layer's routing happens in its combine kernel, the last layer's norm3 and decoder.norm both in the
  * prologue of the output head. */
-int32_t amt_v2_step_decide_batch(const void* const* tab, int32_t n_layers, int32_t H, int32_t E, int32_t dff, int32_t n_exp,
-                                 int32_t S, int32_t max_seq, int32_t B, const float* keys_dev, int32_t* state_dev,
-                                 float* logits_out, float* ws, int64_t* tokens, int64_t* roots, int64_t* attrs, int32_t T,
-                                 int32_t n_primer, int32_t beam, int32_t max_conseq_N, int32_t max_conseq_chord, float temperature,
-                                 const float* uniforms, int32_t chord_embed, int32_t first, void* stream);
+typedef struct amt_v2_step_args {          /* the lockstep step: see amt_v2_step_batch */
+    const void* const* tab;
+    int32_t n_layers, H, E, dff, n_exp, S, max_seq, B;
+    const float* keys_dev; int32_t* state_dev; float* logits_out; float* ws;
+} amt_v2_step_args;
+typedef struct amt_v2_decide_args {        /* the decision: see amt_v2_decide_batch */
+    int64_t* tokens; int64_t* roots; int64_t* attrs;     /* [B][T] */
+    int32_t T, n_primer, beam, max_conseq_N, max_conseq_chord;
+    float temperature;
+    const float* uniforms;                 /* (T, B) or null */
+    int32_t chord_embed;
+} amt_v2_decide_args;
+/* The caller issues at most T - 1 - n_done calls per generation (positions 0 .. T-2); the position counter in state_dev never
+ * advances past T - 1, so a call too many recomputes the last position instead of leaving the caches (T <= max_seq required). */
+int32_t amt_v2_step_decide_batch(const amt_v2_step_args* step, const amt_v2_decide_args* decide, int32_t first, void* stream);
 
 /* ---- regression head VideoRegression(regModel='bimamba+') (model/video_regression.py:104-245) ---- */
 /* Depthwise causal Conv1d(kernel K, padding K-1)[..., :L] + SiLU of MambaBlock.forward (mamba.py:172-175,268-272):

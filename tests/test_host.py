@@ -26,7 +26,22 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} is declared in include/amt_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.load().amt_abi_version() == 1
+    assert _lib.load().amt_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define AMT_ABI_VERSION (\d+)", header).group(1))
+    # release build: no debug entry points, and no environment variable is read by the library (include/amt_hip.h, conventions)
+    import subprocess
+    syms = subprocess.run(["nm", "-D", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "amt_debug" not in syms
+    assert " U getenv" not in syms and " U secure_getenv" not in syms
+
+
+def test_bindings_refuse_a_library_of_another_abi_version(monkeypatch):
+    import importlib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    with pytest.raises(_lib.AmtError, match="ABI version"):
+        _lib.load()
+    monkeypatch.undo()
+    assert _lib.load() is not None
 
 
 def test_bad_config_is_rejected_without_a_gpu():

@@ -364,10 +364,13 @@ def test_skinny_gemm_two_sources_split_and_folded_ffn_prologue():
         D = {k: dev(v) for k, v in dict(x=x, x2=x2, wl=wl, bl=bl, fg=fg, fc=fc, gam=gam, bet=bet).items()}    # keep the device copies alive
         for k, v in dict(resid=resid, wh=wh, bh=bh).items():
             D[k] = dev(v) if v is not None else None
-        P = lambda k, on=True: _lib.ptr(D[k]) if on and D[k] is not None else None
-        _lib.call("amt_decode_gemm_ex_fwd", P("x"), K1, P("x2"), K2, K1, K, P("wl"), P("bl"), P("resid"), 0, P("wh"), P("bh"), n_low, n_high, pro,
-                  P("fg", pro), P("fc", pro), P("gam", pro), P("bet", pro), _lib.ptr(yl), _lib.ptr(yh) if n_high else None,
-                  _lib.ptr(sl), _lib.ptr(sh) if n_high else None, B, 1e-5, sp())
+        A = lambda k, on=True: _lib.addr(D[k]) if on and D[k] is not None else None
+        args = _lib.DecodeGemmArgs(x=A("x"), ldx=K1, x2=A("x2"), ldx2=K2, K1=K1, K=K, w_low=A("wl"), bias_low=A("bl"), resid=A("resid"), relu=0,
+                                   w_high=A("wh"), bias_high=A("bh"), n_low=n_low, n_high=n_high, pro=pro, fold_g=A("fg", pro), fold_c=A("fc", pro),
+                                   ln_w=A("gam", pro), ln_b=A("bet", pro), y_low=_lib.addr(yl), y_high=_lib.addr(yh) if n_high else None,
+                                   scratch_low=_lib.addr(sl), scratch_high=_lib.addr(sh) if n_high else None, B=B, eps=1e-5)
+        import ctypes
+        _lib.call("amt_decode_gemm_ex_fwd", ctypes.byref(args), sp())
         tag = (B, K1, K2, n_low, n_high, pro)
         assert (yl.cpu().double() - ref_low).abs().max().item() < 3e-5, tag
         if n_high:

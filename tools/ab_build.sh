@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B builds for kernel experiments: tools/ab_build.sh TAG [extra hipcc flags]  ->  video2music_amd/lib/libamt_hip.TAG.so
+# A/B builds for kernel experiments: tools/ab_build.sh TAG [extra hipcc flags, e.g. -DAMT_EXPERIMENT to make the library read the AMT_* tuning variables]  ->  video2music_amd/lib/libamt_hip.TAG.so
 # (select at run time with AMT_LIB=video2music_amd/lib/libamt_hip.TAG.so; the default library is untouched)
 set -euo pipefail
 TAG="$1"; shift

@@ -3,7 +3,7 @@
 // reading what the previous one wrote, is captured in a hipGraph and replayed; the stamps of the last replay give, per
 // launch: gap to the previous kernel's last workgroup, first-workgroup start spread, and the median time of each phase.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DAMT_STAMPS tools/ubench_chain.cpp \
-//        video2music_amd/csrc/decode_gemm.hip -o tools/ubench_chain.bin
+//        video2music_amd/csrc/decode_gemm.hip video2music_amd/csrc/tuning.hip -o tools/ubench_chain.bin
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>

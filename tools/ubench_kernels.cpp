@@ -1,5 +1,5 @@
 // Graph-replay micro-benchmark of the decode-step kernels (links the library's kernel files directly).
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/ubench_kernels.cpp video2music_amd/csrc/{decode_gemm,attn_decode,sample}.hip -o tools/ubench_kernels.bin
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/ubench_kernels.cpp video2music_amd/csrc/{decode_gemm,attn_decode,sample,tuning}.hip -o tools/ubench_kernels.bin
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>

@@ -2,7 +2,7 @@
 // prefetch kernel: one workgroup per (clip, head), block id = b*H + h (the attention kernel's (h, b) grid has the same linear
 // id, so under round-robin block->XCD placement both land on the same XCD); plain 16-byte loads of the first `frac` of the
 // head's K and V rows, values discarded.
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/ubench_prefetch.cpp video2music_amd/csrc/attn_decode.hip -o tools/ubench_prefetch.bin
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/ubench_prefetch.cpp video2music_amd/csrc/attn_decode.hip video2music_amd/csrc/tuning.hip -o tools/ubench_prefetch.bin
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>

@@ -3,7 +3,7 @@
 // hipGraph and replayed; diagnostic build (-DAMT_STAMPS) of the library's own kernel files.  Prints, per launch of the last
 // replay: the gap to the previous launch, the span, and the median time of each phase over the launch's workgroups.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DAMT_STAMPS tools/ubench_step.cpp \
-//        video2music_amd/csrc/{decode_gemm,attn_decode}.hip -o tools/ubench_step.bin
+//        video2music_amd/csrc/{decode_gemm,attn_decode,tuning}.hip -o tools/ubench_step.bin
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>

@@ -26,6 +26,23 @@ _P = C.c_void_p
 _I = C.c_int32
 _F = C.c_float
 
+
+class DecodeGemmArgs(C.Structure):           # amt_decode_gemm_args
+    _fields_ = [("x", _P), ("ldx", _I), ("x2", _P), ("ldx2", _I), ("K1", _I), ("K", _I),
+                ("w_low", _P), ("bias_low", _P), ("resid", _P), ("relu", _I), ("w_high", _P), ("bias_high", _P),
+                ("n_low", _I), ("n_high", _I), ("pro", _I), ("fold_g", _P), ("fold_c", _P), ("ln_w", _P), ("ln_b", _P),
+                ("y_low", _P), ("y_high", _P), ("scratch_low", _P), ("scratch_high", _P), ("B", _I), ("eps", _F)]
+
+
+class V2StepArgs(C.Structure):               # amt_v2_step_args
+    _fields_ = [("tab", _P), ("n_layers", _I), ("H", _I), ("E", _I), ("dff", _I), ("n_exp", _I), ("S", _I), ("max_seq", _I), ("B", _I),
+                ("keys_dev", _P), ("state_dev", _P), ("logits_out", _P), ("ws", _P)]
+
+
+class V2DecideArgs(C.Structure):             # amt_v2_decide_args
+    _fields_ = [("tokens", _P), ("roots", _P), ("attrs", _P), ("T", _I), ("n_primer", _I), ("beam", _I), ("max_conseq_N", _I),
+                ("max_conseq_chord", _I), ("temperature", _F), ("uniforms", _P), ("chord_embed", _I)]
+
 # name -> argtypes (restype is int32 unless listed in _RESTYPES); mirrors include/amt_hip.h
 SIGNATURES = {
     "amt_last_error": [],
@@ -48,8 +65,7 @@ SIGNATURES = {
     "amt_generate_end": [_P, _P, _P],
     "amt_generate": [_P, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P],
     "amt_v2_decide_batch": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P],
-    "amt_v2_step_decide_batch": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _I, _I, _P],
-    "amt_debug_set_skip": [_P, _I],
+    "amt_v2_step_decide_batch": [C.POINTER(V2StepArgs), C.POINTER(V2DecideArgs), _I, _P],
     "amt_decode_step_bytes": [_P, _I, _I, _I],
     "amt_linear_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "amt_layernorm_fwd": [_P, _P, _P, _P, _P, _I, _I, _F, _P],
@@ -68,7 +84,7 @@ SIGNATURES = {
     "amt_attn_decode_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "amt_decode_linear_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "amt_attn_decode_fold_fwd": [_P, _I] + [_P] * 10 + [_I, _I, _I, _I, _P, _I, _I, _I, _F, _F, _P],
-    "amt_decode_gemm_ex_fwd": [_P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P],
+    "amt_decode_gemm_ex_fwd": [C.POINTER(DecodeGemmArgs), _P],
     "amt_gqa_fwd": [_P] * 15 + [_I] * 7 + [_F, _P],
     "amt_gqa_rope_fwd": [_P] * 15 + [_I] * 7 + [_F, _P, _I, _I, _P],
     "amt_moe_scratch_floats": [_I, _I, _I, _I],
@@ -94,6 +110,8 @@ _RESTYPES = {"amt_last_error": C.c_char_p, "amt_decode_step_bytes": C.c_int64, "
              "amt_v2_step_ws_floats": C.c_int64, "amt_v2_step_batch_ws_floats": C.c_int64}
 _NO_STATUS = set(_RESTYPES) | {"amt_abi_version"}
 
+ABI_VERSION = 2          # AMT_ABI_VERSION of include/amt_hip.h these prototypes were written against
+
 _lib = None
 
 
@@ -109,6 +127,11 @@ def load():
         raise AmtError(f"{LIB_PATH} is missing: the HIP extension is not built (run __graft_entry__.build()); "
                        "video2music_amd has no CPU fallback")
     lib = C.CDLL(LIB_PATH)
+    lib.amt_abi_version.restype = C.c_int32
+    have = lib.amt_abi_version()
+    if have != ABI_VERSION:
+        raise AmtError(f"{LIB_PATH} implements ABI version {have}, these bindings need {ABI_VERSION}: rebuild the library "
+                       "(__graft_entry__.build())")
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
@@ -125,6 +148,14 @@ def call(name, *args):
         msg = lib.amt_last_error()
         raise AmtError(f"{name} failed (status {rc}): {msg.decode() if msg else '?'}")
     return rc
+
+
+def addr(t):
+    """Device address of a (contiguous) tensor as a plain int / None: the form a ctypes Structure field of type c_void_p takes."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "libamt_hip takes contiguous tensors"
+    return t.data_ptr()
 
 
 def ptr(t):

@@ -28,7 +28,7 @@ void amt_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* amt_last_error(void) { return g_err; }
-extern "C" int32_t amt_abi_version(void) { return 1; }
+extern "C" int32_t amt_abi_version(void) { return AMT_ABI_VERSION; }
 
 // ------------------------------------------------------------------------------------------------
 // handle
@@ -37,7 +37,6 @@ namespace {
 
 constexpr int V = 159;
 constexpr float LN_EPS = 1e-5f;
-constexpr int STEPS_PER_GRAPH = 8;
 constexpr int VS = 160;                  // V rounded up to the skinny GEMM's 16-column tiles
 
 struct Tensor {
@@ -108,7 +107,8 @@ struct amt_handle {
     bool chord_embed = false;            // amt_set_option("chord_embed"): the chord id is the input index and feeds back
     bool causal_mask = true;             // amt_set_option("causal_mask"): 0 = the forward without the subsequent mask (mask=False)
     const float* vis_resid = nullptr;    // amt_encode_resid: rows added to Linear_vis's output (scene_embed)
-    int skip_mask = 0;                   // bench-only ablation: 1 = no self-attention launches, 2 = no cross-attention launches
+    int skip_mask = 0;                   // amt_set_option("profile_skip"): measurement ablation, 1 = no self-attention launches, 2 = no cross-attention launches
+    bool plain_chain = false;            // amt_set_option("decode_chain_plain"), before the first amt_finalize: the 49-launch chain without folded LayerNorms
     bool gen_active = false;
     // graphs keyed by the parameters baked into the captured kernel arguments
     struct GraphKey { int B, T, P, beam, mcN, mcC, S, nsteps, skip, pad; float* logits; };
@@ -555,8 +555,7 @@ extern "C" int32_t amt_finalize(amt_handle* h) {
         h->kx_rows = h->Scap;                    // (300 rows: not a power-of-two stride; an extra row measured no gain)
         h->kvx_part = (size_t)h->nl * h->maxB * h->H * h->kx_rows * h->hd;
         h->kvx_layer = (size_t)h->maxB * h->H * h->kx_rows * h->hd;
-        h->kv_rows = h->Tcap | 1;
-        if (const char* e = getenv("AMT_KV_PAD")) h->kv_rows = h->Tcap + atoi(e);      // experiments: 0 = the aliased power-of-two stride
+        h->kv_rows = amt_tuning().kv_pad >= 0 ? h->Tcap + amt_tuning().kv_pad : (h->Tcap | 1);    // (experiments: 0 = the aliased power-of-two stride)
         h->kvc_part = (size_t)h->nl * h->maxB * h->H * h->kv_rows * h->hd;
         h->kvc_layer = (size_t)h->maxB * h->H * h->kv_rows * h->hd;
         if ((rc = dev_alloc(h, &h->KVx, 2 * h->kvx_part))) return rc;
@@ -580,8 +579,7 @@ extern "C" int32_t amt_finalize(amt_handle* h) {
         if ((rc = dev_alloc(h, &h->ob, bd))) return rc;
         if ((rc = dev_alloc(h, &h->hb, mb * dff))) return rc;
         // folded chain: K = 2d and dff + d must fit the skinny GEMM, d the attention prologue
-        const char* chain = getenv("AMT_DECODE_CHAIN");
-        h->fold = !(chain && strcmp(chain, "plain") == 0) && d % 32 == 0 && 2 * d <= 1536 && (dff + d) % 64 == 0 && dff + d <= 1536 && dff % 16 == 0;   // G1 / G2 read [o | x]: K = 2d
+        h->fold = !h->plain_chain && d % 32 == 0 && 2 * d <= 1536 && (dff + d) % 64 == 0 && dff + d <= 1536 && dff % 16 == 0;   // G1 / G2 read [o | x]: K = 2d
         if (h->fold) {
             if ((rc = dev_alloc(h, &h->qraw, bd))) return rc;
             if ((rc = dev_alloc(h, &h->hraw, mb * dff))) return rc;
@@ -680,6 +678,16 @@ extern "C" int32_t amt_set_option(amt_handle* h, const char* name, int32_t value
     }
     if (strcmp(name, "causal_mask") == 0) {                  // run-time switch of amt_prefill (forward(mask=False), :978-982)
         h->causal_mask = value != 0;
+        return 0;
+    }
+    if (strcmp(name, "decode_chain_plain") == 0) {           // the 49-launch decode chain (also the fall-back of shapes the fold does not cover)
+        AMT_CHECK_ARG(!h->KVx || h->plain_chain == (value != 0), "amt_set_option: decode_chain_plain must be chosen before the first amt_finalize");
+        h->plain_chain = value != 0;
+        return 0;
+    }
+    if (strcmp(name, "profile_skip") == 0) {                 // measurement hook of bench.py: leave a kernel class out of the captured step
+        AMT_CHECK_ARG(value >= 0 && value < 4, "amt_set_option: profile_skip takes 0 (none), 1 (self-attention), 2 (cross-attention) or 3");
+        h->skip_mask = value;
         return 0;
     }
     AMT_CHECK_ARG(false, "amt_set_option: unknown option '%s'", name);
@@ -853,8 +861,7 @@ extern "C" int32_t amt_generate_run(amt_handle* h, int32_t n_steps, float* logit
     if (n_steps < 0 || n_steps > remaining) n_steps = remaining;
     int32_t rc;
     int left = n_steps;
-    static int spg = 0;
-    if (!spg) { const char* e = getenv("AMT_STEPS_PER_GRAPH"); spg = e && atoi(e) > 0 ? atoi(e) : STEPS_PER_GRAPH; }
+    const int spg = amt_tuning().steps_per_graph;
     while (left > 0) {
         const int ns = left >= spg ? spg : 1;
         hipGraphExec_t exec;
@@ -956,12 +963,6 @@ extern "C" int32_t amt_generate(amt_handle* h, int32_t B, const int64_t* primer,
     if (rc) return rc;
     if ((rc = amt_generate_run(h, -1, logits_out, stream))) return rc;
     return amt_generate_end(h, tokens_out, stream);
-}
-
-extern "C" int32_t amt_debug_set_skip(amt_handle* h, int32_t mask) {
-    AMT_CHECK_ARG(h && mask >= 0 && mask < 4, "amt_debug_set_skip: bad argument");
-    h->skip_mask = mask;
-    return 0;
 }
 
 extern "C" int64_t amt_decode_step_bytes(const amt_handle* h, int32_t B, int32_t n_self_keys, int32_t S) {
@@ -1109,25 +1110,21 @@ extern "C" int32_t amt_attn_decode_fold_fwd(const float* raw, int32_t ldq, float
     return amt_launch_attn_decode(a, (hipStream_t)stream);
 }
 
-extern "C" int32_t amt_decode_gemm_ex_fwd(const float* x, int32_t ldx, const float* x2, int32_t ldx2, int32_t K1, int32_t K,
-                                          const float* w_low, const float* bias_low, const float* resid, int32_t relu,
-                                          const float* w_high, const float* bias_high, int32_t n_low, int32_t n_high,
-                                          int32_t pro, const float* fold_g, const float* fold_c, const float* ln_w, const float* ln_b,
-                                          float* y_low, float* y_high, float* scratch_low, float* scratch_high,
-                                          int32_t B, float eps, void* stream) {
-    AMT_CHECK_ARG(x && w_low && y_low && scratch_low && n_low > 0 && n_low % 16 == 0, "amt_decode_gemm_ex_fwd: bad low part");
-    AMT_CHECK_ARG(n_high == 0 || (w_high && y_high && scratch_high && x2), "amt_decode_gemm_ex_fwd: incomplete high part");
+extern "C" int32_t amt_decode_gemm_ex_fwd(const amt_decode_gemm_args* a, void* stream) {
+    AMT_CHECK_ARG(a, "amt_decode_gemm_ex_fwd: null argument block");
+    AMT_CHECK_ARG(a->x && a->w_low && a->y_low && a->scratch_low && a->n_low > 0 && a->n_low % 16 == 0, "amt_decode_gemm_ex_fwd: bad low part");
+    AMT_CHECK_ARG(a->n_high == 0 || (a->w_high && a->y_high && a->scratch_high && a->x2), "amt_decode_gemm_ex_fwd: incomplete high part");
     hipStream_t s = (hipStream_t)stream;
-    const int Klow = x2 ? K1 : K;
+    const int Klow = a->x2 ? a->K1 : a->K;
     int32_t rc;
-    if ((rc = amt_launch_pack_weight(w_low, scratch_low, n_low, Klow, s))) return rc;
-    if (n_high > 0 && (rc = amt_launch_pack_weight(w_high, scratch_high, n_high, K, s))) return rc;
+    if ((rc = amt_launch_pack_weight(a->w_low, a->scratch_low, a->n_low, Klow, s))) return rc;
+    if (a->n_high > 0 && (rc = amt_launch_pack_weight(a->w_high, a->scratch_high, a->n_high, a->K, s))) return rc;
     DecodeGemmParams g{};
-    g.B = B; g.eps = eps; g.scale = 1.f; g.x = x; g.ldx = ldx; g.x2 = x2; g.ldx2 = ldx2; g.K1 = K1; g.K = K;
-    g.Wp = scratch_low; g.bias = bias_low; g.resid = resid; g.ldr = n_low; g.relu = relu; g.y = y_low; g.ldy = n_low;
-    g.pro = pro; g.fold_g = fold_g; g.fold_c = fold_c; g.ln_w = ln_w; g.ln_b = ln_b;
-    g.N = n_low + n_high;
-    if (x2) { g.n_split = n_low; g.Wp2 = scratch_high; g.bias2 = bias_high; g.y2 = y_high; g.ldy2 = n_high; }
+    g.B = a->B; g.eps = a->eps; g.scale = 1.f; g.x = a->x; g.ldx = a->ldx; g.x2 = a->x2; g.ldx2 = a->ldx2; g.K1 = a->K1; g.K = a->K;
+    g.Wp = a->scratch_low; g.bias = a->bias_low; g.resid = a->resid; g.ldr = a->n_low; g.relu = a->relu; g.y = a->y_low; g.ldy = a->n_low;
+    g.pro = a->pro; g.fold_g = a->fold_g; g.fold_c = a->fold_c; g.ln_w = a->ln_w; g.ln_b = a->ln_b;
+    g.N = a->n_low + a->n_high;
+    if (a->x2) { g.n_split = a->n_low; g.Wp2 = a->scratch_high; g.bias2 = a->bias_high; g.y2 = a->y_high; g.ldy2 = a->n_high; }
     return amt_launch_decode_gemm(g, s);
 }
 
@@ -1136,9 +1133,7 @@ extern "C" int32_t amt_decode_linear_fwd(const float* x, const float* w, const f
                                          int32_t B, int32_t N, int32_t K, int32_t relu, float eps, void* stream) {
     AMT_CHECK_ARG(x && w && y && w_packed_scratch, "amt_decode_linear_fwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    int dbg = 0;
-    if (const char* e = getenv("AMT_DBG")) dbg = atoi(e);          // micro-benchmarks only
-    if (!(dbg & 16)) {                                             // 16: scratch already holds the packed weight
+    if (!amt_tuning().prepacked) {                                 // (micro-benchmarks of an experiment build: scratch already holds the packed weight)
         int32_t rc = amt_launch_pack_weight(w, w_packed_scratch, N, K, s);
         if (rc) return rc;
     }

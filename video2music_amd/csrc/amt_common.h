@@ -81,3 +81,22 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- tuning constants of the launch heuristics ----
+// One immutable, process-wide record.  The release build returns the defaults below (what every committed number was measured
+// with).  A build with -DAMT_EXPERIMENT (tools/ab_build.sh TAG -DAMT_EXPERIMENT) reads each field ONCE, under std::call_once,
+// from the environment variable named beside it -- the A/B switches of DESIGN.md section 9; the release library reads no
+// environment variable and keeps no other mutable global besides the per-device attribute flags guarded by mutexes.
+struct AmtTuning {
+    int kv_pad = -1;              // AMT_KV_PAD: padding rows per (clip, head) slice of the self-attention cache; -1 = make Tcap odd
+    int steps_per_graph = 8;      // AMT_STEPS_PER_GRAPH: decode steps per captured hipGraph
+    int nt_mask = 3;              // AMT_NT: non-temporal K/V loads, bit 0 self-attention, bit 1 cross-attention
+    int wide_grouped = 1;         // AMT_WIDE_GROUPED: grouped down-projections on the wide skinny GEMM
+    int wide_ntw = 4;             // AMT_WIDE_NTW: column tiles per workgroup of the wide skinny GEMM
+    long gemm_small_m = 4096;     // AMT_GEMM_SMALL_M / AMT_GEMM_SMALL_MN: dense products at or below go to the skinny GEMM
+    long gemm_small_mn = 650000;
+    int gemm_t64_below = 768;     // AMT_GEMM_T64_BELOW: fewer 128x128 tiles than this take the 64x64 instantiation
+    int gemm_pf = 22;             // AMT_GEMM_PF: prefetch distances (tens: big tile, units: small tile)
+    int prepacked = 0;            // AMT_DBG bit 4: amt_decode_linear_fwd finds the packed weight in its scratch (micro-benchmarks)
+};
+const AmtTuning& amt_tuning();

@@ -333,9 +333,8 @@ void launch_decode_u(const AttnDecodeParams& p, hipStream_t stream) {
     dim3 grid(p.H, p.B);
     // K/V are streamed once per launch and exceed the 256 MiB Infinity Cache per step: non-temporal loads keep
     // the step's re-used bytes (weights, activations) resident instead (measured +8 % tokens/s at
-    // config 2).  AMT_NT overrides for experiments: bit 0 = self-attention, bit 1 = cross-attention.
-    static int nt_mask = -1;
-    if (nt_mask < 0) { const char* e = getenv("AMT_NT"); nt_mask = e ? atoi(e) : 3; }
+    // config 2).  AmtTuning::nt_mask: bit 0 = self-attention, bit 1 = cross-attention.
+    const int nt_mask = amt_tuning().nt_mask;
     if (p.Er) {
         if (nt_mask & 1) hipLaunchKernelGGL((attn_decode_kernel<HD, true, true, FOLD, UCH>), grid, dim3(NW * 64), 0, stream, p);
         else hipLaunchKernelGGL((attn_decode_kernel<HD, true, false, FOLD, UCH>), grid, dim3(NW * 64), 0, stream, p);

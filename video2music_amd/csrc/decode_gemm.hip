@@ -569,14 +569,12 @@ int32_t amt_launch_decode_gemm(const DecodeGemmParams& p_in, hipStream_t stream)
     // wide plain products: several column tiles per workgroup (see decode_gemm_wide_kernel)
     // the grouped down projections of a mixture layer (gated prologue): more workgroups than the chip holds at once with one
     // tile each, one round with two
-    static int wide_grp = -1;
-    if (wide_grp < 0) { const char* e = getenv("AMT_WIDE_GROUPED"); wide_grp = e ? atoi(e) : 1; }
+    const int wide_grp = amt_tuning().wide_grouped;
     if (wide_grp > 0 && p.n_groups > 1 && p.glu_gate && !p.ln_w && p.pro == 0 && !p.rope && !p.x2 && p.mode == 0 && p.ldw == 0 && !p.sel &&
         (p.K == 512 || p.K == 1024) && cdiv(p.N, 16) * cdiv(p.B, MT) * p.n_groups > 256) {
         return p.K == 512 ? launch_wide<2, 3, 2>(p, stream) : launch_wide<4, 3, 2>(p, stream);
     }
-    static int wide_ntw = -1;
-    if (wide_ntw < 0) { const char* e = getenv("AMT_WIDE_NTW"); wide_ntw = e ? atoi(e) : 4; }
+    const int wide_ntw = amt_tuning().wide_ntw;
     if (wide_ntw > 0 && p.N >= 4096 && !p.x2 && p.n_split == 0 && !p.sel && p.n_groups <= 1 && p.mode == 0 && !p.rope && !p.glu_gate && p.pro == 0 &&
         p.ldw == 0 && (p.K == 512 || p.K == 1024) && (!p.ln_w || p.ln_b) && !p.ln2_w) {
         const bool ln = p.ln_w != nullptr;

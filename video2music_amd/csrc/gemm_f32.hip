@@ -252,13 +252,7 @@ int32_t amt_launch_gemm(const GemmParams& p, hipStream_t stream) {
     // fewer tiles than CUs nothing hides it.  With a plain epilogue they go to the skinny GEMM (16x16 output tiles, all of a
     // workgroup's weight loads in flight at once): ~10 us up to M*N = 256k outputs, break-even with the 64x64-tile variant below
     // near 650k outputs (tools/bench_small_gemm.py).
-    static long small_m = -1, small_mn = -1;
-    if (small_m < 0) {
-        const char* e = getenv("AMT_GEMM_SMALL_M");
-        small_m = e ? atol(e) : 4096;
-        const char* f = getenv("AMT_GEMM_SMALL_MN");
-        small_mn = f ? atol(f) : 650000;
-    }
+    const long small_m = amt_tuning().gemm_small_m, small_mn = amt_tuning().gemm_small_mn;
     if (p.M <= small_m && (long)p.M * p.N <= small_mn && p.K % 32 == 0 && p.K <= 1536 && !p.head_split && !p.rowadd && !p.silu_mul &&
         !p.sigmoid && !p.tile_group && !p.a_gather && p.relu != 2) {
         DecodeGemmParams g{};
@@ -270,10 +264,8 @@ int32_t amt_launch_gemm(const GemmParams& p, hipStream_t stream) {
     // model (K <= 1312; 114-126 TFLOP/s at M = 32768, 111 at M = 9600 since the loads of the k loop are branch-free and two
     // k-tiles ahead: tools/bench_gemm.py; 103-110 before); the big tile is kept for long-K products with many tiles.
     const int t128 = cdiv(p.M, 128) * cdiv(p.N, 128);
-    static int t64_below = -1;
-    if (t64_below < 0) { const char* e = getenv("AMT_GEMM_T64_BELOW"); t64_below = e ? atoi(e) : 768; }
-    static int pf = -1;
-    if (pf < 0) { const char* e = getenv("AMT_GEMM_PF"); pf = e ? atoi(e) : 22; }      // tens: big tile, units: small tile
+    const int t64_below = amt_tuning().gemm_t64_below;
+    const int pf = amt_tuning().gemm_pf;                 // tens: big tile, units: small tile
     const bool big = t128 >= t64_below && p.K >= 2048;
     const dim3 g64(cdiv(p.M, 64) * cdiv(p.N, 64));
     if (p.a_gather) {

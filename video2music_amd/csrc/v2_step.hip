@@ -485,16 +485,14 @@ extern "C" int32_t amt_v2_step_batch(const void* const* tab, int32_t n_layers, i
     return v2_step_batch_impl(tab, n_layers, H, E, dff, n_exp, S, max_seq, B, keys_dev, state_dev, logits_out, ws, stream, true, true);
 }
 
-extern "C" int32_t amt_v2_step_decide_batch(const void* const* tab, int32_t n_layers, int32_t H, int32_t E, int32_t dff, int32_t n_exp,
-                                            int32_t S, int32_t max_seq, int32_t B, const float* keys_dev, int32_t* state_dev,
-                                            float* logits_out, float* ws, int64_t* tokens, int64_t* roots, int64_t* attrs, int32_t T,
-                                            int32_t n_primer, int32_t beam, int32_t max_conseq_N, int32_t max_conseq_chord, float temperature,
-                                            const float* uniforms, int32_t chord_embed, int32_t first, void* stream) {
-    int32_t rc = v2_step_batch_impl(tab, n_layers, H, E, dff, n_exp, S, max_seq, B, keys_dev, state_dev, logits_out, ws, stream, first != 0, false);
+extern "C" int32_t amt_v2_step_decide_batch(const amt_v2_step_args* st, const amt_v2_decide_args* dc, int32_t first, void* stream) {
+    AMT_CHECK_ARG(st && dc, "amt_v2_step_decide_batch: null argument block");
+    AMT_CHECK_ARG(dc->T <= st->max_seq, "amt_v2_step_decide_batch: T=%d exceeds the caches' %d rows", dc->T, st->max_seq);
+    int32_t rc = v2_step_batch_impl(st->tab, st->n_layers, st->H, st->E, st->dff, st->n_exp, st->S, st->max_seq, st->B, st->keys_dev, st->state_dev,
+                                    st->logits_out, st->ws, stream, first != 0, false);
     if (rc) return rc;
-    auto G = [&](int i) { return (const float*)tab[i]; };
-    return amt_launch_v2_decide_fused(logits_out, 159, state_dev, tokens, roots, attrs, B, T, n_primer, beam, max_conseq_N, max_conseq_chord,
-                                      temperature, uniforms, chord_embed, keys_dev, G(G_PR), G(G_PA), G(G_WKEY), G(G_CBIAS), G(G_PE), ws, E,
-                                      (hipStream_t)stream);
+    auto G = [&](int i) { return (const float*)st->tab[i]; };
+    return amt_launch_v2_decide_fused(st->logits_out, 159, st->state_dev, dc->tokens, dc->roots, dc->attrs, st->B, dc->T, dc->n_primer, dc->beam,
+                                      dc->max_conseq_N, dc->max_conseq_chord, dc->temperature, dc->uniforms, dc->chord_embed, st->keys_dev, G(G_PR),
+                                      G(G_PA), G(G_WKEY), G(G_CBIAS), G(G_PE), st->ws, st->E, (hipStream_t)stream);
 }
-

@@ -198,6 +198,9 @@ class VideoMusicTransformer(nn.Module):
             _lib.call("amt_create", C.byref(cfg), C.byref(h))
             if self.chord_embed:
                 _lib.call("amt_set_option", h, b"chord_embed", 1)
+            # diagnostic: the decode step without folded LayerNorms (the library itself reads no environment variable)
+            if getattr(self, "decode_chain", None) == "plain" or os.environ.get("AMT_DECODE_CHAIN") == "plain":
+                _lib.call("amt_set_option", h, b"decode_chain_plain", 1)
             self._handle = h
             self._weights_sig = None
         sig = tuple((k, v.data_ptr(), v._version) for k, v in self.state_dict().items()) + (bool(IS_SEPERATED),)
@@ -403,7 +406,7 @@ class VideoMusicTransformer(nn.Module):
 
     def _debug_set_skip(self, mask):
         """bench.py only: leave the self- (1) / cross- (2) attention launches out of the decode step."""
-        _lib.call("amt_debug_set_skip", self._ensure_handle(), int(mask))
+        _lib.call("amt_set_option", self._ensure_handle(), b"profile_skip", int(mask))
 
     def generate_profile(self, feature_semantic_list, feature_key, feature_scene_offset, feature_motion, feature_emotion,
                          primer, primer_root, primer_attr, target_seq_length=300, max_conseq_N=0, max_conseq_chord=2):
@@ -1179,13 +1182,16 @@ class VideoMusicTransformer_V2(nn.Module):
         state = torch.zeros(2 + 2 * nb, dtype=torch.int32, device=dev)          # {position, root[B], attr[B], ticket}
         state[1:1 + 2 * nb] = torch.cat((gen_root[:, 0], gen_attr[:, 0])).to(torch.int32)
 
+        A = _lib.addr
+        step_args = _lib.V2StepArgs(C.cast(st["tab"], C.c_void_p), len(self.transformer.decoder.layers), self.nhead, self.d_model, st["dff"],
+                                    self.n_experts, st["S"], self._max_dec, st["B"], A(keys), A(state), A(st["logits"]), A(st["ws"]))
+        decide_args = _lib.V2DecideArgs(A(tokens), A(roots), A(attrs), T, P, int(beam), int(max_conseq_N), int(max_conseq_chord),
+                                        float(temperature), A(unif), int(bool(self.chord_embed)))
+
         def step(first):
             # one launch chain: the decoder step, then the decision, the next position's chord-stream row and the position
             # advance in one kernel (amt_v2_step_decide_batch; `first`: the chain starts with the embedding of position 0)
-            _lib.call("amt_v2_step_decide_batch", st["tab"], len(self.transformer.decoder.layers), self.nhead, self.d_model, st["dff"],
-                      self.n_experts, st["S"], self._max_dec, st["B"], _lib.ptr(keys), _lib.ptr(state), _lib.ptr(st["logits"]),
-                      _lib.ptr(st["ws"]), _lib.ptr(tokens), _lib.ptr(roots), _lib.ptr(attrs), T, P, int(beam), int(max_conseq_N),
-                      int(max_conseq_chord), float(temperature), _lib.ptr(unif), int(bool(self.chord_embed)), int(first), _lib.stream_ptr())
+            _lib.call("amt_v2_step_decide_batch", C.byref(step_args), C.byref(decide_args), int(first), _lib.stream_ptr())
 
         step(True)                                                      # position 0 (the warm-up a capture needs)
         if T > 2:
