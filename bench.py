@@ -116,8 +116,8 @@ def make_model(cfg, device, seed=0):
 def cpu_baseline(cfg, sd, T, budget_s=25.0):
     """Per-length cost of one step of the reference loop (full re-forward incl. encoder, no KV
     cache, B=1: model/video_music_transformer.py:1069-1071) integrated over the T-1 steps of a clip.
-    Timed with all of this GPU's host-core share (16 threads) and, coarser, with 8 threads (SURVEY.md §8(d):
-    comparable with the survey container's figures)."""
+    Timed with the intra-op thread count that a short calibration finds fastest on this host (8 ... 128 candidates) and, coarser,
+    with 8 threads (comparable with the survey container's figures)."""
     from oracle import amt_oracle as O
     prev_threads = torch.get_num_threads()
     feats = synthetic.synthetic_features(1, seed=99)
@@ -141,19 +141,38 @@ def cpu_baseline(cfg, sd, T, budget_s=25.0):
                 cost.append(best)
         return float(np.trapezoid(np.interp(np.arange(1, T), lengths, cost)))
 
-    # the GPU box gives one GPU a 16-CPU share; more intra-op threads only add overhead at these sizes
-    threads = min(16, os.cpu_count() or 1)
+    # thread count: calibrated here, not assumed -- one forward at L = T/4 per candidate (profiles/r03_cpu_baseline_thread_sweep.json
+    # is the same sweep recorded at L = 512 on the GPU box); the best candidate is the baseline's `cores`
+    ncpu = os.cpu_count() or 1
+    cands = [n for n in (8, 16, 32, 64, 128) if n <= ncpu] or [ncpu]
+    calib = {}
+    rs = np.random.RandomState(1)
+    Lc = max(T // 4, 1)
+    root = torch.from_numpy(rs.randint(1, 13, size=(1, Lc)))
+    attr = torch.from_numpy(rs.randint(1, 14, size=(1, Lc)))
+    with torch.no_grad():
+        for n in cands:
+            torch.set_num_threads(n)
+            best = float("inf")
+            for _ in range(2):
+                t0 = time.perf_counter()
+                O.forward(sd, cfg["num_heads"], root, attr, f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"])
+                best = min(best, time.perf_counter() - t0)
+            calib[n] = best
+    threads = min(calib, key=calib.get)
     lengths = sorted({1, T // 16, T // 8, T // 4, (3 * T) // 8, T // 2, (5 * T) // 8, (3 * T) // 4, (7 * T) // 8, T - 1})
     per_clip = per_clip_seconds(threads, lengths, budget_s)
     coarse = sorted({1, T // 4, T // 2, (3 * T) // 4, T - 1})
-    per_clip8 = per_clip_seconds(min(8, threads), coarse, budget_s * 0.5)
+    per_clip8 = per_clip_seconds(min(8, ncpu), coarse, budget_s * 0.5)
     torch.set_num_threads(prev_threads)
     return {"value": round((T - 1) / per_clip, 3), "unit": "chord-tokens/s", "cores": threads, "kind": "port",
             "sample": f"oracle forward (no KV cache, encoder re-run, B=1) timed at L={lengths} (best of 2-3), "
                       f"integrated over the {T - 1} steps of one clip = {per_clip:.1f} s/clip; clips run sequentially",
             "value_8_threads": round((T - 1) / per_clip8, 3),
-            "sample_8_threads": f"same, {min(8, threads)} threads, L={coarse} (best of 2): {per_clip8:.1f} s/clip",
-            "host_cpus": os.cpu_count()}
+            "sample_8_threads": f"same, {min(8, ncpu)} threads, L={coarse} (best of 2): {per_clip8:.1f} s/clip",
+            "thread_calibration_s_per_forward": {str(n): round(v, 4) for n, v in calib.items()},
+            "thread_calibration": f"one oracle forward at L={Lc} per candidate thread count (best of 2); `cores` = the fastest",
+            "host_cpus": ncpu}
 
 
 def _sha256(path):
@@ -353,6 +372,51 @@ def whole_step(cfg, B, T, st, generate_ms):
                     "by the launch chain, the streaming kernels by HBM"}
 
 
+def v2_lockstep_leg(device, B=32, T=300, reps=3):
+    """SURVEY.md §8(f1): the reference's DEFAULT model family (`-music_gen_version 2.2`, utilities/argument_generate_funcs.py:82;
+    model/video_music_transformer.py:316-609: rotary attention, three GLU layers + three SharedMoE(6 experts, top-2) layers) at the
+    bench's width, decoded for B clips in lockstep to the reference's default length T = 300 (one captured step + decision graph,
+    feedback-greedy).  Whole generate incl. video encode and cache initialisation; fp32."""
+    from video2music_amd import _lib
+    from video2music_amd.model.video_music_transformer import VideoMusicTransformer_V2
+    cfg = dict(version_name="2.2", n_layers=6, num_heads=8, d_model=512, dim_feedforward=1024, max_sequence_chord=T,
+               total_vf_dim=synthetic.total_vf_dim(1))
+    m = VideoMusicTransformer_V2(**cfg).eval()
+    shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=0).items()})
+    m = m.to(device)
+    f = {k: torch.from_numpy(v).to(device) for k, v in synthetic.synthetic_features(B, seed=5).items()}
+    pr = [torch.tensor([v]) for v in C.primer_from_name("C")]
+
+    def run(t):
+        return m.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], *pr, target_seq_length=t, beam=0,
+                                sampler="argmax")
+
+    with torch.no_grad():
+        run(8)
+        run(T)
+        torch.cuda.synchronize(device)
+        best = float("inf")
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            out = run(T)
+            torch.cuda.synchronize(device)
+            best = min(best, time.perf_counter() - t0)
+        short = float("inf")
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            run(T // 3)
+            torch.cuda.synchronize(device)
+            short = min(short, time.perf_counter() - t0)
+    launches = int(_lib.call("amt_v2_last_step_launches"))
+    return {"model": "VideoMusicTransformer_V2('2.2') 6+6 layers d_model=512 H=8 dff=1024, 6 experts top-2 + shared in layers 3-5",
+            "batch": B, "seq_len": T, "tokens_per_s": round(B * (T - 1) / best, 1), "generate_ms": round(1e3 * best, 2),
+            "launches_per_step": launches, "us_per_step_from_slope": round(1e6 * (best - short) / (T - T // 3), 2),
+            "distinct_ids": len(set(out.flatten().tolist())), "dtype": "f32", "data": "synthetic",
+            "measured": f"wall clock around generate_batch (encode + cache initialisation + {T - 1} replayed steps), best of {reps}; "
+                        "the per-step figure is the slope between T and T/3"}
+
+
 def rehearsal(args, rank, world):
     """AMT_BENCH_REHEARSAL=1 (tests/test_dist_gloo.py, no GPU): the launcher, the barriers, the one all_gather and the
     MAX-over-ranks reduction with fabricated ids in place of the generate.  The line says so and carries no rate."""
@@ -434,6 +498,8 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_roofline:
         result["roofline"] = roofline(model, f, (pr, prr, pra), B, T, cfg)
+    if rank == 0 and world == 1 and not args.no_roofline:
+        result["v2_lockstep"] = v2_lockstep_leg(device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, sd, T)
     if rank == 0:

@@ -301,7 +301,7 @@ int32_t amt_moe_combine_fwd(const float* y_rows, const int32_t* slot_pos, const 
  * amt_pack_weight_fwd (out: ceil(N/16)*16*K floats; the experts of a MoE layer are packed one after the other).
  * tab: device pointers, 11 global (PR, PA, wkey, Linear_chord.bias, rope cache (max_seq, E/2, 2) or null = no rotation,
  * decoder.norm w, b, packed Wout, Wout b, an int32 pair {0, 1}, learned positional table (max_seq, E) added to the
- * embedding of position t or null: version '2.0' has the table and no rotation, :375-380,497-503) then 40 per layer (packed self in_proj, its bias, packed out_proj, b,
+ * embedding of position t or null: version '2.0' has the table and no rotation, :375-380,497-503) then 48 per layer (packed self in_proj, its bias, packed out_proj, b,
  * norm1 w, b, packed cross in_proj rows 0:E, its bias, packed out_proj, b, norm2 w, b, norm3 w, b, self K cache, V cache
  * (head-major: H, max_seq, hd), cross K (roped), V (head-major: H, S, hd), router w (null = plain GLU layer), router b, packed linear1, b, packed gate, b,
  * packed linear2, b (per expert, stacked, for a MoE layer), shared expert's six tensors (packed weights) or null; then, for the
@@ -309,7 +309,12 @@ int32_t amt_moe_combine_fwd(const float* y_rows, const int32_t* slot_pos, const 
  * and its bias, packed linear2 of every expert (+ shared) one after the other and their biases (both null for a plain GLU layer,
  * whose linear2 is the per-layer entry above); last, for the lockstep step with norm1 folded through the cross-attention's query
  * projection (all four null: separate launches): packed [(Wq o gamma1) Wo | Wq o gamma1] (E x 2E), its bias (Wq o gamma1) bo,
- * g = rowsum(Wq o gamma1), c = Wq beta1 + bq  (Wo, bo: self-attention out-projection; Wq, bq: cross in_proj rows 0:E)).
+ * g = rowsum(Wq o gamma1), c = Wq beta1 + bq  (Wo, bo: self-attention out-projection; Wq, bq: cross in_proj rows 0:E)); and, for
+ * a plain GLU layer of the lockstep step with norm2 and norm3 folded (all eight null: separate launches; E and dff multiples of
+ * 256, dff + E <= 1536): packed [(Wgu o gamma2) Wo | Wgu o gamma2] (2 dff x 2E; Wgu = [gate; linear1], Wo the cross-attention's
+ * out-projection), its bias (Wgu o gamma2) bo, g = rowsum(Wgu o gamma2), c = Wgu beta2 + bgu, then -- null in the last layer --
+ * packed [(Wn o gamma3) W2 | Wn o gamma3] (3E x (dff + E); Wn the NEXT layer's self in_proj, W2 this layer's linear2), its bias
+ * (Wn o gamma3) b2, g = rowsum(Wn o gamma3), c = Wn beta3 + bn.
  * A null norm bias selects RMSNorm (eps 1e-6) for that norm; a null linear1 selects Linear -> SiLU -> Linear experts
  * (h = silu(gate-slot projection)): the V1 family (video_music_transformer.py:22-314).
  * ws: amt_v2_step_ws_floats(E, dff, n_exp) floats.  E, dff multiples of 64, at most 1536.
@@ -371,6 +376,9 @@ typedef struct amt_v2_decide_args {        /* the decision: see amt_v2_decide_ba
 /* The caller issues at most T - 1 - n_done calls per generation (positions 0 .. T-2); the position counter in state_dev never
  * advances past T - 1, so a call too many recomputes the last position instead of leaving the caches (T <= max_seq required). */
 int32_t amt_v2_step_decide_batch(const amt_v2_step_args* step, const amt_v2_decide_args* decide, int32_t first, void* stream);
+/* Introspection for bench.py: kernel launches issued by the calling thread's last amt_v2_step_batch / amt_v2_step_decide_batch
+ * call (a count, not a status). */
+int32_t amt_v2_last_step_launches(void);
 
 /* ---- regression head VideoRegression(regModel='bimamba+') (model/video_regression.py:104-245) ---- */
 /* Depthwise causal Conv1d(kernel K, padding K-1)[..., :L] + SiLU of MambaBlock.forward (mamba.py:172-175,268-272):

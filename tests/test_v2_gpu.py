@@ -313,3 +313,45 @@ def test_v2_feed_forward_narrower_than_half_the_model_width(d, H, ff, nl):
         assert torch.equal(toks[b:b + 1], ref), (b, toks[b], ref)
         if b == 0:
             assert torch.equal(one, ref)
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("d,H,ff,nl,version", [(256, 4, 256, 4, "2.2"), (256, 4, 512, 4, "2.2"), (512, 8, 512, 4, "2.2"), (512, 8, 1024, 4, "2.0")])
+def test_v2_plain_layers_with_folded_norms(monkeypatch, d, H, ff, nl, version, mode):
+    """The lockstep step of a plain GLU layer with norm3 folded through the next layer's QKV projection (mode 1, the default: the down
+    projection takes rows [up * silu(gate) | x] and emits the raw QKV product, the next self-attention finishes q / k / v with the row
+    statistics, rotates q and the new key -- attention prologue 4; '2.0' has no rotation and takes prologue 2) and, mode 2, norm2 through
+    the stacked gate | up product as well (skinny-GEMM prologue 5 at K = 512 / 768 / 1024 / 1536): ids equal to the chain with the
+    folds switched off and, for '2.2', to the oracle clip by clip."""
+    cfg = dict(CFG_V2, version_name=version, n_layers=nl, num_heads=H, d_model=d, dim_feedforward=ff)
+    fc = feats_t(synthetic.synthetic_features(3, seed=d + ff))
+    f = {k: v.cuda() for k, v in fc.items()}
+    pr = (torch.tensor([1]), torch.tensor([1]), torch.tensor([0]))
+    T = 14
+    outs = {}
+    for fold in (mode, "0"):
+        monkeypatch.setenv("AMT_V2_FOLD_FFN", fold)
+        m = VideoMusicTransformer_V2(**cfg).eval()
+        shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+        sd = {k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=d + ff, recipe="feedback").items()}
+        m.load_state_dict(sd)
+        m = m.cuda()
+        with torch.no_grad():
+            outs[fold] = m.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], *pr, target_seq_length=T,
+                                          beam=0, sampler="argmax").cpu()
+            if fold != "0":
+                st = m._cache_init([torch.zeros(300, d, device="cuda")], 300)
+                n_qkv = sum(1 for li in range(nl) if st["tab"][11 + 48 * li + 44] is not None)
+                n_gu = sum(1 for li in range(nl) if st["tab"][11 + 48 * li + 40] is not None)
+                assert (n_qkv, n_gu) == (3, 3 if mode == "2" else 0), (n_qkv, n_gu)      # the three shallow GLU layers carry the folded entries
+    assert torch.equal(outs[mode], outs["0"])
+    assert len(set(outs[mode][:, 1:].flatten().tolist())) >= 4
+    if version != "2.2":
+        return                      # (the oracle's V2 forward is the rotary one; '2.0' is pinned by its own goldens)
+    for b in range(3):
+        c = {k: v[b:b + 1] for k, v in fc.items()}
+        margins = []
+        ref = O.generate(sd, H, c["semantic"], c["key"], c["scene_offset"], c["motion"], c["emotion"], *pr, target_seq_length=T, beam=0,
+                         forward_fn=O.forward_v2, margins=margins)
+        assert min(margins) > 1e-3, margins
+        assert torch.equal(outs[mode][b:b + 1], ref), (b, outs[mode][b], ref)

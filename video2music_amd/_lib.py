@@ -104,11 +104,12 @@ SIGNATURES = {
     "amt_v2_step": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P],
     "amt_rnn_seq_fwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "amt_v2_step_batch_ws_floats": [_I, _I, _I, _I],
+    "amt_v2_last_step_launches": [],
     "amt_v2_step_batch": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
 }
 _RESTYPES = {"amt_last_error": C.c_char_p, "amt_decode_step_bytes": C.c_int64, "amt_moe_scratch_floats": C.c_int64, "amt_moe_topk_scratch_floats": C.c_int64,
              "amt_v2_step_ws_floats": C.c_int64, "amt_v2_step_batch_ws_floats": C.c_int64}
-_NO_STATUS = set(_RESTYPES) | {"amt_abi_version"}
+_NO_STATUS = set(_RESTYPES) | {"amt_abi_version", "amt_v2_last_step_launches"}
 
 ABI_VERSION = 2          # AMT_ABI_VERSION of include/amt_hip.h these prototypes were written against
 
@@ -167,5 +168,10 @@ def ptr(t):
 
 
 def stream_ptr():
+    """The calling thread's current HIP stream as void* (torch.cuda.current_stream().cuda_stream, through the raw accessor: the
+    Stream object costs ~7 us per call, which adds up in the host-bound phases -- a few hundred operator calls per generate)."""
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    try:
+        return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    except AttributeError:          # another torch build
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -93,10 +93,12 @@ struct AmtTuning {
     int nt_mask = 3;              // AMT_NT: non-temporal K/V loads, bit 0 self-attention, bit 1 cross-attention
     int wide_grouped = 1;         // AMT_WIDE_GROUPED: grouped down-projections on the wide skinny GEMM
     int wide_ntw = 4;             // AMT_WIDE_NTW: column tiles per workgroup of the wide skinny GEMM
+    int wide_rb2 = 1;             // AMT_WIDE_RB2: 17-32 rows of a wide product in one workgroup (both row blocks share the weight tiles)
     long gemm_small_m = 4096;     // AMT_GEMM_SMALL_M / AMT_GEMM_SMALL_MN: dense products at or below go to the skinny GEMM
     long gemm_small_mn = 650000;
     int gemm_t64_below = 768;     // AMT_GEMM_T64_BELOW: fewer 128x128 tiles than this take the 64x64 instantiation
     int gemm_pf = 22;             // AMT_GEMM_PF: prefetch distances (tens: big tile, units: small tile)
+    int exp_a = 0, exp_b = 0;     // free switches for the experiment of the day (amt_experiment_set, experiment builds only)
     int prepacked = 0;            // AMT_DBG bit 4: amt_decode_linear_fwd finds the packed weight in its scratch (micro-benchmarks)
 };
 const AmtTuning& amt_tuning();

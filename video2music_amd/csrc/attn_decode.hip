@@ -107,7 +107,8 @@ __device__ __forceinline__ void stream_keys(Batch<HD>& cur, Batch<HD>& nxt, cons
 constexpr int UCH_MAX = 4;       // folded prologue: the pre-LN row has at most UCH*256 floats (UCH = 2 or 4 by the model's width)
 
 // FOLD: 0 plain query, 1 folded-LayerNorm prologue, 2 the same plus the new key/value of this position, 3 = 1 plus the rotary
-// embedding of the query (the lockstep V1/V2 step: q = rope(LayerNorm(u) . Wq^T + b) * scale)
+// embedding of the query (the lockstep V1/V2 step: q = rope(LayerNorm(u) . Wq^T + b) * scale), 4 = 2 plus the rotary embedding of
+// the query and of the new key (the V1/V2 self-attention behind a folded norm3; no relative-position table)
 #ifdef AMT_STAMPS
 #define ASTAMP(i) do { __builtin_amdgcn_sched_barrier(0); st_[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -144,7 +145,7 @@ void attn_decode_kernel(AttnDecodeParams p) {
     int j0 = wave * KPW;
     const int t = p.pos ? *p.pos : (p.n_keys - 1);   // issued here: the prologue's stores would pin it behind them
     float4 q4, kn4 = make_float4(0.f, 0.f, 0.f, 0.f), vn4 = kn4;
-    constexpr bool fresh = FOLD == 2;             // key/value of position t live in registers, not in the cache
+    constexpr bool fresh = FOLD == 2 || FOLD == 4;   // key/value of position t live in registers, not in the cache
     const int n_keys = fresh ? t : t + 1;
     const float* eb = RPR ? p.Er + (size_t)(p.er_len - 1 - t) * HD : nullptr;   // Er row of key 0 (wave-uniform)
     // Vector loads return in issue order.  The long prologue of FOLD 2 (11 loads and their address math) goes
@@ -171,16 +172,17 @@ void attn_decode_kernel(AttnDecodeParams p) {
         const float* raw = p.q + (size_t)b * p.ldq + col;
         const float4 rq = ld4(raw), gq = ld4(p.fold_g + col), cq = ld4(p.fold_c + col);
         float4 rk = kn4, gk = kn4, ck = kn4, rv = kn4, gv = kn4, cv = kn4;
-        if (FOLD == 2) {
+        if (fresh) {
             rk = ld4(raw + d); gk = ld4(p.fold_g + d + col); ck = ld4(p.fold_c + d + col);
             rv = ld4(raw + 2 * d); gv = ld4(p.fold_g + 2 * d + col); cv = ld4(p.fold_c + 2 * d + col);
         }
         float4 rcs = make_float4(1.f, 0.f, 1.f, 0.f);
         if (FOLD == 3) rcs = ld4(p.rope + (size_t)(*p.rope_pos) * p.rope_dim + (col % p.rope_dim));     // (cos, sin) of the lane's two pairs
+        if (FOLD == 4) rcs = ld4(p.rope + (size_t)t * p.rope_dim + (col % p.rope_dim));
         if (F1) load_kv<HD, NT>(b0, kb, vb, j0, sub, c4, p.cap);
         // the first batch's Er rows need only the position: issued behind the prologue's loads, they land while the
         // statistics are reduced instead of costing one more L2 round trip after the query exists
-        if (RPR && FOLD == 2) load_er<HD>(b0, eb, j0, sub, c4, n_keys);
+        if (RPR && fresh) load_er<HD>(b0, eb, j0, sub, c4, n_keys);
         __builtin_amdgcn_sched_barrier(0);             // no consumer of a loaded value moves in front of the loads above
         const float inv_d = 1.0f / (float)d;
         float s = 0.f;
@@ -197,7 +199,7 @@ void attn_decode_kernel(AttnDecodeParams p) {
             }
         }
         const float rstd = rsqrtf(wave_sum(qq) * inv_d + p.eps);
-        if (FOLD == 3) {
+        if (FOLD == 3 || FOLD == 4) {
             // interleaved pairs (2i, 2i+1): even y = x*c - x'*s, odd y = x'*c + x*s (the skinny GEMM's rotary epilogue), then the scale
             const float x0 = (rq.x - mean * gq.x) * rstd + cq.x, x1 = (rq.y - mean * gq.y) * rstd + cq.y;
             const float x2 = (rq.z - mean * gq.z) * rstd + cq.z, x3 = (rq.w - mean * gq.w) * rstd + cq.w;
@@ -207,9 +209,14 @@ void attn_decode_kernel(AttnDecodeParams p) {
             q4.x = ((rq.x - mean * gq.x) * rstd + cq.x) * p.q_scale; q4.y = ((rq.y - mean * gq.y) * rstd + cq.y) * p.q_scale;
             q4.z = ((rq.z - mean * gq.z) * rstd + cq.z) * p.q_scale; q4.w = ((rq.w - mean * gq.w) * rstd + cq.w) * p.q_scale;
         }
-        if (FOLD == 2) {
+        if (fresh) {
             kn4.x = (rk.x - mean * gk.x) * rstd + ck.x; kn4.y = (rk.y - mean * gk.y) * rstd + ck.y;
             kn4.z = (rk.z - mean * gk.z) * rstd + ck.z; kn4.w = (rk.w - mean * gk.w) * rstd + ck.w;
+            if (FOLD == 4) {                      // the key is rotated like the query (no scale)
+                const float k0 = kn4.x, k1 = kn4.y, k2 = kn4.z, k3 = kn4.w;
+                kn4.x = k0 * rcs.x - k1 * rcs.y; kn4.y = k1 * rcs.x + k0 * rcs.y;
+                kn4.z = k2 * rcs.z - k3 * rcs.w; kn4.w = k3 * rcs.z + k2 * rcs.w;
+            }
             vn4.x = (rv.x - mean * gv.x) * rstd + cv.x; vn4.y = (rv.y - mean * gv.y) * rstd + cv.y;
             vn4.z = (rv.z - mean * gv.z) * rstd + cv.z; vn4.w = (rv.w - mean * gv.w) * rstd + cv.w;
         }
@@ -243,7 +250,7 @@ void attn_decode_kernel(AttnDecodeParams p) {
         st4(p.k_new + (((size_t)b * p.H + h) * p.cap + t) * HD + c * 4, kn4);
         st4(p.v_new + (((size_t)b * p.H + h) * p.cap + t) * HD + c * 4, vn4);
     }
-    if (RPR && FOLD != 2) load_er<HD>(b0, eb, j0, sub, c4, n_keys);
+    if (RPR && !fresh) load_er<HD>(b0, eb, j0, sub, c4, n_keys);
     float m = -INFINITY, l = 0.f;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!RPR) {
@@ -336,8 +343,10 @@ void launch_decode_u(const AttnDecodeParams& p, hipStream_t stream) {
     // config 2).  AmtTuning::nt_mask: bit 0 = self-attention, bit 1 = cross-attention.
     const int nt_mask = amt_tuning().nt_mask;
     if (p.Er) {
-        if (nt_mask & 1) hipLaunchKernelGGL((attn_decode_kernel<HD, true, true, FOLD, UCH>), grid, dim3(NW * 64), 0, stream, p);
-        else hipLaunchKernelGGL((attn_decode_kernel<HD, true, false, FOLD, UCH>), grid, dim3(NW * 64), 0, stream, p);
+        if constexpr (FOLD != 4) {               // (the rotary self-attention has no relative-position table: checked by the launcher)
+            if (nt_mask & 1) hipLaunchKernelGGL((attn_decode_kernel<HD, true, true, FOLD, UCH>), grid, dim3(NW * 64), 0, stream, p);
+            else hipLaunchKernelGGL((attn_decode_kernel<HD, true, false, FOLD, UCH>), grid, dim3(NW * 64), 0, stream, p);
+        }
     } else {
         if (nt_mask & 2) hipLaunchKernelGGL((attn_decode_kernel<HD, false, true, FOLD, UCH>), grid, dim3(NW * 64), 0, stream, p);
         else hipLaunchKernelGGL((attn_decode_kernel<HD, false, false, FOLD, UCH>), grid, dim3(NW * 64), 0, stream, p);
@@ -363,7 +372,16 @@ int32_t amt_launch_attn_decode(const AttnDecodeParams& p, hipStream_t stream) {
                       "attn_decode: bad folded prologue (d=%d ldq=%d)", p.d, p.ldq);
         AMT_CHECK_ARG(!p.xn || (p.fold_lnw && p.fold_lnb), "attn_decode: xn needs the LayerNorm affine");
         AMT_CHECK_ARG(!p.new_kv || (p.pos && p.k_new && p.v_new && p.ldq >= 3 * p.d), "attn_decode: new_kv needs pos, the cache and 3d raw columns");
-        if (p.new_kv) {
+        if (p.new_kv && p.rope) {
+            AMT_CHECK_ARG(!p.Er && p.rope_dim > 0 && p.rope_dim % 4 == 0, "attn_decode: the rotary self-attention takes no relative-position table");
+            switch (p.hd) {
+                case 16: launch_decode<16, 4>(p, stream); break;
+                case 32: launch_decode<32, 4>(p, stream); break;
+                case 64: launch_decode<64, 4>(p, stream); break;
+                case 128: launch_decode<128, 4>(p, stream); break;
+                default: AMT_CHECK_ARG(false, "attn_decode: head_dim %d not in {16,32,64,128}", p.hd);
+            }
+        } else if (p.new_kv) {
             switch (p.hd) {
                 case 16: launch_decode<16, 2>(p, stream); break;
                 case 32: launch_decode<32, 2>(p, stream); break;

@@ -53,7 +53,8 @@ __device__ __forceinline__ float sq4(const float4 a, float m) {
 }
 
 // KCH = float4 chunks per lane and row (K <= KCH*256) = weight tiles per wave; FULL: K == KCH*256, no lane
-// predicates; PRO: 0 plain rows, 1 LayerNorm prologue, 2 folded-FFN prologue.
+// predicates; PRO: 0 plain rows, 1 LayerNorm prologue, 2 folded-FFN prologue, 3 gated-linear-unit prologue, 4 two LayerNorms,
+// 5 folded gated FFN prologue (2 with a gate: up * silu(gate) in place of the ReLU).
 //
 // Everything the kernel reads from global memory is issued up front in ONE branch-free sequence: rows, prologue
 // vectors, weight tiles, epilogue operands (out-of-range lanes read a clamped address and discard the value).
@@ -78,7 +79,8 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
     float* xs = smem;                               // [16][LD]
     // [16 waves][4 r][64 lanes] partial tiles in a region of their own (behind the staged rows and the folded-FFN vectors): a wave stores its
     // partials as soon as its MFMAs are done, with no barrier in between (sharing the rows' region cost one: +0.6 % tokens/s without it)
-    float* red = smem + MT * LD + (PRO == 2 ? 2 * K : 0);
+    constexpr bool FFN = PRO == 2 || PRO == 5;       // folded-FFN prologues: per-column vectors handed over through LDS
+    float* red = smem + MT * LD + (PRO == 2 ? 2 * K : PRO == 5 ? 2 * K + 2 * p.K1 : 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, m0 = blockIdx.y * MT;
     // column split: tiles below n_split multiply the first K1 input columns by Wp, the others all K by Wp2
@@ -100,14 +102,22 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
         const int i = (c * 64 + lane) * 4, ic = FULL ? i : min(i, K - 4);
         v[c] = ld4((ic < K1 ? xr : x2r) + ic);
     }
-    float4 gv[PRO == 3 ? KCH : 1];
+    // PRO 5: at least one 256-column chunk belongs to the u half (two at K = 1536, where the launcher asks for K - K1 >= 512: one
+    // float4 more per lane would spill at the 128-VGPR budget of a 16-wave workgroup)
+    constexpr int GCH = PRO == 5 ? (KCH == 6 ? 4 : KCH > 1 ? KCH - 1 : 1) : KCH;
+    float4 gv[(PRO == 3 || PRO == 5) ? GCH : 1];
     if (PRO == 3) {
         const float* gr = p.glu_gate + (size_t)zg * p.x_group_off + (size_t)rc * p.ldx;
 #pragma unroll
         for (int c = 0; c < KCH; ++c) {
             const int i = (c * 64 + lane) * 4, ic = FULL ? i : min(i, K - 4);
-            gv[c] = ld4(gr + ic);
+            gv[c] = ld4(gr + min(ic, K1 - 4));       // (two-source rows: the chunks past K1 are not gated and re-read the last gate chunk)
         }
+    }
+    if (PRO == 5) {                                   // raw gate columns of the first K1 staged columns (chunks past K1 re-read the last one)
+        const float* gr = p.glu_gate + (size_t)rc * p.ldx;
+#pragma unroll
+        for (int c = 0; c < GCH; ++c) gv[c] = ld4(gr + min((c * 64 + lane) * 4, K1 - 4));
     }
     // ---- 2. prologue vectors ----
     constexpr bool LN1 = PRO == 1 || PRO == 4;      // PRO 4: two LayerNorms in a row (norm3 of the last layer, then decoder.norm)
@@ -131,11 +141,15 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
     // folded FFN: the per-column vectors (same for all 16 rows) go through LDS, one float4 per thread (K/2 <= 1024)
     float4 gs_val = make_float4(0.f, 0.f, 0.f, 0.f);
     const int gs_t = min(tid, K / 2 - 1), gs_vec = gs_t >= K / 4, gs_i = (gs_t - gs_vec * (K / 4)) * 4;
-    if (PRO == 2) {
+    if (FFN) {
         const float* a = gs_i < K1 ? p.fold_g + gs_i : p.ln_w + (gs_i - K1);
         const float* b = gs_i < K1 ? p.fold_c + gs_i : p.ln_b + (gs_i - K1);
         gs_val = ld4(gs_vec ? b : a);
     }
+    // folded gated FFN: the gate's two vectors [g2 (K1) | c2 (K1)], one more float4 for the first K1/2 threads (clamped)
+    float4 gs2_val = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int gs2_t = min(tid, K1 / 2 - 1), gs2_vec = gs2_t >= K1 / 4, gs2_i = (gs2_t - gs2_vec * (K1 / 4)) * 4;
+    if (PRO == 5) gs2_val = ld4((gs2_vec ? p.fold_c2 : p.fold_g2) + gs2_i);
     // ---- 3. this wave's weight tiles (tile index clamped: surplus loads repeat the last tile) ----
     float4 wt[KCH];
     const int grp = p.sel ? *p.sel : zg;            // device-chosen weight group (mixture-of-experts, one token) or the launch's group
@@ -154,11 +168,12 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
     const int row = m0 + 4 * (el >> 4) + er, n = nt * 16 + (el & 15);
     const bool live = tid < 256 && row < p.B && n < p.N;
     // ---- prologue math ----
-    if (PRO == 2) {
-        // [ relu((raw - mu*g)*rstd + c) | LayerNorm(u) ], statistics over the u half (columns K1..K-1)
-        float* gs = smem + MT * LD;                 // [2][K]: g|gamma , c|beta
+    if (FFN) {
+        // [ relu((raw - mu*g)*rstd + c) | LayerNorm(u) ], statistics over the u half (columns K1..K-1); PRO 5: up * silu(gate) for the ReLU
+        float* gs = smem + MT * LD;                 // [2][K]: g|gamma , c|beta  (PRO 5: then [2][K1]: the gate's g2 , c2)
         st4(gs + gs_vec * K + gs_i, gs_val);        // unconditional (surplus threads repeat the last float4): a guarded
                                                     // store lets the compiler sink the load behind the weight loads
+        if (PRO == 5) st4(gs + 2 * K + gs2_vec * K1 + gs2_i, gs2_val);
         const float inv_n = 1.0f / (float)(K - K1);
         float um[KCH];                              // 1 on the u half, 0 elsewhere (a multiply keeps the loops branch-free)
 #pragma unroll
@@ -183,9 +198,19 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
             // a 256-column chunk lies on one side of K1 in every shape the model builds (K1 = dim_feedforward, a multiple of 256
             // at config 2; 256 at config 1): the side is then wave-uniform and each half takes its own short formula
             if (256 * c + 256 <= K1) {               // raw half: relu((raw - mu*g)*rstd + c)
+                if (PRO == 5 && c < GCH) {           // up * silu(gate), both finished with the same row statistics
+                    const float4 g2 = ld4(gs + 2 * K + ic), h2 = ld4(gs + 2 * K + K1 + ic);
+                    const float ux = (v[c].x - mean * g.x) * rstd + h.x, uy = (v[c].y - mean * g.y) * rstd + h.y;
+                    const float uz = (v[c].z - mean * g.z) * rstd + h.z, uw = (v[c].w - mean * g.w) * rstd + h.w;
+                    const float tx = (gv[c].x - mean * g2.x) * rstd + h2.x, ty = (gv[c].y - mean * g2.y) * rstd + h2.y;
+                    const float tz = (gv[c].z - mean * g2.z) * rstd + h2.z, tw = (gv[c].w - mean * g2.w) * rstd + h2.w;
+                    v[c].x = ux * (tx / (1.0f + __expf(-tx))); v[c].y = uy * (ty / (1.0f + __expf(-ty)));
+                    v[c].z = uz * (tz / (1.0f + __expf(-tz))); v[c].w = uw * (tw / (1.0f + __expf(-tw)));
+                } else if (PRO != 5) {
                 v[c].x = fmaxf((v[c].x - mean * g.x) * rstd + h.x, 0.f); v[c].y = fmaxf((v[c].y - mean * g.y) * rstd + h.y, 0.f);
                 v[c].z = fmaxf((v[c].z - mean * g.z) * rstd + h.z, 0.f); v[c].w = fmaxf((v[c].w - mean * g.w) * rstd + h.w, 0.f);
-            } else if (256 * c >= K1) {              // LayerNorm half: (u - mu)*rstd*gamma + beta
+                }
+            } else if (256 * c >= K1 || PRO == 5) {  // LayerNorm half: (u - mu)*rstd*gamma + beta  (PRO 5: K1 is a multiple of 256)
                 v[c].x = (v[c].x - mean) * rstd * g.x + h.x; v[c].y = (v[c].y - mean) * rstd * g.y + h.y;
                 v[c].z = (v[c].z - mean) * rstd * g.z + h.z; v[c].w = (v[c].w - mean) * rstd * g.w + h.w;
             } else {                                 // K1 inside the chunk: one branch-free form for both (x*1.0f is exact)
@@ -227,6 +252,8 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
         const float um = p.glu_only ? 0.f : 1.f, uo = p.glu_only ? 1.f : 0.f;      // h = u * silu(g), or silu(g) alone
 #pragma unroll
         for (int c = 0; c < KCH; ++c) {
+            // two-source rows [x * silu(gate) (K1 columns) | x2]: whole 256-column chunks on either side (checked by the launcher)
+            if (p.x2 && 256 * c + 256 > K1) continue;
             v[c].x = (v[c].x * um + uo) * (gv[c].x / (1.0f + __expf(-gv[c].x))); v[c].y = (v[c].y * um + uo) * (gv[c].y / (1.0f + __expf(-gv[c].y)));
             v[c].z = (v[c].z * um + uo) * (gv[c].z / (1.0f + __expf(-gv[c].z))); v[c].w = (v[c].w * um + uo) * (gv[c].w / (1.0f + __expf(-gv[c].w)));
         }
@@ -244,10 +271,10 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
     // next to a pending load (packed VALU ops read register pairs).  Absent operands read a zero word instead of
     // being masked after the load: a select on a loaded value would be scheduled early and wait for the weights ----
     const float* bp = high ? p.bias2 : (p.bias ? p.bias + (size_t)grp * p.sel_b_stride : nullptr);      // (grp = blockIdx.z in a grouped launch)
-    const bool has_b = live && bp != nullptr, has_r = PRO != 2 && live && !high && p.mode == 0 && p.resid != nullptr;
+    const bool has_b = live && bp != nullptr, has_r = !FFN && live && !high && p.mode == 0 && p.resid != nullptr;
     const float e_bias = *(has_b ? bp + (high ? n - p.n_split : n) : p.zero);
     float e_res = 0.f;
-    if (PRO != 2) e_res = *(has_r ? p.resid + (size_t)row * p.ldr + n : p.zero);
+    if (!FFN) e_res = *(has_r ? p.resid + (size_t)row * p.ldr + n : p.zero);
     const int t = *(p.pos ? p.pos : reinterpret_cast<const int*>(p.zero));
 
     // the normalised rows are the residual of the following block: workgroup (nt, m-block) publishes its
@@ -259,7 +286,7 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
             if (m0 + rr < p.B) p.xn[(size_t)(m0 + rr) * K + cb + c] = xs[rr * LD + cb + c];
     }
     // folded FFN: the LayerNorm half of the staged row is the residual of the low columns
-    if (PRO == 2 && live && !high) e_res = xs[(row - m0) * LD + K1 + n];
+    if (FFN && live && !high) e_res = xs[(row - m0) * LD + K1 + n];
 
     // ---- main: 4 MFMAs per k-tile ----
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -487,6 +514,164 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_wide_kernel(DecodeGemmPar
     }
 }
 
+// The wide product for up to 32 rows in ONE workgroup (RB2): both 16-row blocks share the workgroup's weight tiles, so a tile
+// group's weights cross L2 -> L1 once instead of once per row block, and the launch is half as many workgroups -- the stacked
+// gate | up product of a mixture layer at 32 clips (1792 column tiles, K = 512) becomes 224 workgroups = ONE round over the chip
+// instead of 448 = two (13.6 -> 11.3 us in the lockstep step's trace; lockstep V2 generate 97.6 -> 96.2 ms alternating in one
+// process, profiles/r03_v2_ab.json).  Wave w stages rows w and 16 + w;
+// per k-tile a weight fragment feeds two MFMA chains; the partial tiles of the two row blocks go through the same LDS region one
+// after the other.  Same arithmetic per output as decode_gemm_wide_kernel (bit-identical results).  K = KCH * 256 <= 512.
+template <int KCH, int PRO, int NTW>
+__global__ __launch_bounds__(NW * 64) void decode_gemm_wide2_kernel(DecodeGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int K = KCH * 256, LD = K + XPAD, kt_n = K / 16;
+    float* xs = smem;                               // [2][16][LD]
+    float* red = smem + 2 * MT * LD;                // [NTW][16 waves][256] partial tiles of ONE row block at a time
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_tiles = (p.N + 15) >> 4;
+    const int grp = (int)blockIdx.x;
+    if (grp * NTW >= n_tiles) return;
+    const int nt0 = grp * NTW;
+    const int kt0 = wave * KCH;
+    float4 v[2][KCH];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const float* xr = p.x + (size_t)min(rb * MT + wave, p.B - 1) * p.ldx;
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) v[rb][c] = ld4(xr + (c * 64 + lane) * 4);
+    }
+    float4 g0[PRO == 1 ? KCH : 1], h0[PRO == 1 ? KCH : 1];
+    if (PRO == 1) {
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            g0[c] = ld4(p.ln_w + (c * 64 + lane) * 4);
+            h0[c] = ld4(p.ln_b + (c * 64 + lane) * 4);
+        }
+    }
+    float4 wt[NTW][KCH];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const float* wbase = p.Wp + (size_t)min(nt0 + j, n_tiles - 1) * kt_n * 256;      // surplus tiles repeat the last one
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) wt[j][i] = ld4(wbase + ((size_t)(kt0 + i) * 64 + lane) * 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (PRO == 1) {
+        const float inv_k = 1.0f / (float)K;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) s += sum4(v[rb][c]);
+            const float mean = wave_sum(s) * inv_k;
+            float q = 0.f;
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) q += sq4(v[rb][c], mean);
+            const float rstd = rsqrtf(wave_sum(q) * inv_k + p.eps);
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) {
+                v[rb][c].x = (v[rb][c].x - mean) * rstd * g0[c].x + h0[c].x; v[rb][c].y = (v[rb][c].y - mean) * rstd * g0[c].y + h0[c].y;
+                v[rb][c].z = (v[rb][c].z - mean) * rstd * g0[c].z + h0[c].z; v[rb][c].w = (v[rb][c].w - mean) * rstd * g0[c].w + h0[c].w;
+            }
+        }
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) st4(xs + (rb * MT + wave) * LD + (c * 64 + lane) * 4, v[rb][c]);
+    __syncthreads();
+
+    // thread (jg, e) owns output e of tiles nt0 + jg, nt0 + jg + 4, ... of each row block
+    constexpr int JN = (NTW + 3) / 4;
+    const int jg = tid >> 8, e = tid & 255;
+    const int el = e & 63, er = (e >> 6) & 3;
+    const int rloc = 4 * (el >> 4) + er;
+    float e_bias[JN];
+#pragma unroll
+    for (int q = 0; q < JN; ++q) {
+        const int j = jg + 4 * q, n = (nt0 + j) * 16 + (el & 15);
+        e_bias[q] = *((j < NTW && n < p.N && p.bias) ? p.bias + n : p.zero);
+        if (PRO == 1 && p.xn && j < NTW && (nt0 + j) * 16 < K) {
+            const int rr = e >> 4, c = e & 15;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+                if (rb * MT + rr < p.B) p.xn[(size_t)(rb * MT + rr) * K + (nt0 + j) * 16 + c] = xs[(rb * MT + rr) * LD + (nt0 + j) * 16 + c];
+        }
+    }
+
+    f32x4 acc[2][NTW];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* xa = xs + (lane & 15) * LD + kt0 * 16 + 4 * (lane >> 4);
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+        const float4 a0 = ld4(xa + i * 16), a1 = ld4(xa + MT * LD + i * 16);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const float4 w = wt[j][i];
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w.x, acc[0][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, w.y, acc[0][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, w.z, acc[0][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, w.w, acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, w.x, acc[1][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, w.y, acc[1][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, w.z, acc[1][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, w.w, acc[1][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        if (rb) __syncthreads();                    // the first row block's partial tiles are consumed
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            float* rw = red + (j * NW + wave) * 256;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) rw[rr * 64 + lane] = acc[rb][j][rr];
+        }
+        __syncthreads();
+        const int row = rb * MT + rloc;
+#pragma unroll
+        for (int q = 0; q < JN; ++q) {
+            const int j = jg + 4 * q, n = (nt0 + j) * 16 + (el & 15);
+            if (j < NTW) {
+                float val = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) val += red[(j * NW + w) * 256 + e];
+                val += e_bias[q];
+                if (row < p.B && n < p.N) {
+                    if (n < p.scale_cols) val *= p.scale;
+                    if (p.resid) val += p.resid[(size_t)row * p.ldr + n];
+                    if (p.relu) val = fmaxf(val, 0.f);
+                    p.y[(size_t)row * p.ldy + n] = val;
+                }
+            }
+        }
+    }
+}
+
+template <int KCH, int PRO, int NTW>
+int32_t launch_wide2(const DecodeGemmParams& p, hipStream_t stream) {
+    static bool attr_set[64] = {false};
+    static std::mutex mu;
+    int dev = 0;
+    AMT_HIP(hipGetDevice(&dev));
+    AMT_CHECK_ARG(dev >= 0 && dev < 64, "decode_gemm: device ordinal %d out of range", dev);
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!attr_set[dev]) {
+            AMT_HIP(hipFuncSetAttribute((const void*)decode_gemm_wide2_kernel<KCH, PRO, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set[dev] = true;
+        }
+    }
+    constexpr size_t lds = (size_t)2 * MT * (KCH * 256 + XPAD) * sizeof(float) + (size_t)NTW * NW * 256 * sizeof(float);      // rows of both blocks | partial tiles
+    static_assert(lds <= 160 * 1024, "rows + partial tiles must fit the 160 KiB of LDS");
+    hipLaunchKernelGGL((decode_gemm_wide2_kernel<KCH, PRO, NTW>), dim3(cdiv(cdiv(p.N, 16), NTW)), dim3(NW * 64), lds, stream, p);
+    AMT_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int KCH, int PRO, int NTW>
 int32_t launch_wide(const DecodeGemmParams& p, hipStream_t stream) {
     static bool attr_set[64] = {false};
@@ -512,6 +697,7 @@ int32_t launch_wide(const DecodeGemmParams& p, hipStream_t stream) {
 template <int KCH, bool FULL>
 int32_t launch_variant(const DecodeGemmParams& p, size_t lds, hipStream_t stream) {
     if (p.pro == 1) return launch_one<KCH, FULL, 2>(p, lds, stream);
+    if (p.pro == 2) { if constexpr (FULL && KCH >= 2) return launch_one<KCH, FULL, 5>(p, lds, stream); }
     if (p.glu_gate) return launch_one<KCH, FULL, 3>(p, lds, stream);
     if (p.ln_w && p.ln2_w) { if constexpr (KCH <= 4) return launch_one<KCH, FULL, 4>(p, lds, stream); }
     if (p.ln_w) { if constexpr (KCH <= 4) return launch_one<KCH, FULL, 1>(p, lds, stream); }
@@ -561,10 +747,18 @@ int32_t amt_launch_decode_gemm(const DecodeGemmParams& p_in, hipStream_t stream)
     AMT_CHECK_ARG(!p.sel || p.n_split == 0, "decode_gemm: a device-selected weight group cannot be combined with a column split");
     AMT_CHECK_ARG(p.ldw == 0 || (p.ldw >= p.K && p.ldw % 4 == 0 && p.n_split == 0 && !p.sel), "decode_gemm: bad un-packed weight (ldw=%d)", p.ldw);
     AMT_CHECK_ARG(p.n_groups <= 1 || (!p.sel && p.n_split == 0 && !p.x2 && p.ldw == 0 && !p.resid && p.mode == 0 && p.n_groups <= 65535), "decode_gemm: a grouped launch takes plain single-source products");
-    AMT_CHECK_ARG(!p.glu_gate || (!p.x2 && !p.ln_w && p.pro == 0), "decode_gemm: the gated prologue takes a single source and no LayerNorm");
+    AMT_CHECK_ARG(!p.glu_gate || p.pro == 2 || (!p.ln_w && p.pro == 0 && (!p.x2 || (p.K1 % 256 == 0 && p.K % 256 == 0 && p.n_groups <= 1 && !p.glu_only))),
+                  "decode_gemm: the gated prologue takes no LayerNorm, and a second source only behind whole 256-column chunks");
     AMT_CHECK_ARG(!p.rope || (p.pos && p.rope_dim > 0 && p.rope_dim % 2 == 0 && p.rope_cols % 2 == 0 && p.n_split == 0), "decode_gemm: bad rotary epilogue");
-    if (p.pro == 1) AMT_CHECK_ARG(p.x2 && p.fold_g && p.fold_c && p.ln_w && p.ln_b && !p.resid, "decode_gemm: incomplete folded-FFN prologue");
-    else AMT_CHECK_ARG(!p.ln_w || (!p.x2 && p.K <= 1024), "decode_gemm: the LayerNorm prologue takes a single source of K <= 1024");
+    if (p.pro == 2) {
+        AMT_CHECK_ARG(p.x2 && p.glu_gate && p.fold_g && p.fold_c && p.fold_g2 && p.fold_c2 && p.ln_w && p.ln_b && !p.resid && p.K1 % 256 == 0 &&
+                      (p.K == 512 || p.K == 768 || p.K == 1024 || (p.K == 1536 && p.K - p.K1 >= 512)) && p.n_groups <= 1 && !p.sel && p.ldw == 0,
+                      "decode_gemm: incomplete folded gated-FFN prologue (K1=%d K=%d)", p.K1, p.K);
+    } else if (p.pro == 1) {
+        AMT_CHECK_ARG(p.x2 && p.fold_g && p.fold_c && p.ln_w && p.ln_b && !p.resid, "decode_gemm: incomplete folded-FFN prologue");
+    } else {
+        AMT_CHECK_ARG(!p.ln_w || (!p.x2 && p.K <= 1024), "decode_gemm: the LayerNorm prologue takes a single source of K <= 1024");
+    }
     AMT_CHECK_ARG(!p.ln2_w || (p.ln_w && p.ln_b && p.ln2_b && p.pro == 0 && !p.glu_gate), "decode_gemm: the second LayerNorm follows a first one");
     // wide plain products: several column tiles per workgroup (see decode_gemm_wide_kernel)
     // the grouped down projections of a mixture layer (gated prologue): more workgroups than the chip holds at once with one
@@ -578,6 +772,8 @@ int32_t amt_launch_decode_gemm(const DecodeGemmParams& p_in, hipStream_t stream)
     if (wide_ntw > 0 && p.N >= 4096 && !p.x2 && p.n_split == 0 && !p.sel && p.n_groups <= 1 && p.mode == 0 && !p.rope && !p.glu_gate && p.pro == 0 &&
         p.ldw == 0 && (p.K == 512 || p.K == 1024) && (!p.ln_w || p.ln_b) && !p.ln2_w) {
         const bool ln = p.ln_w != nullptr;
+        // 17 .. 32 rows: both row blocks in one workgroup (half the workgroups, the weights through L1 once)
+        if (p.K == 512 && p.B > MT && p.B <= 2 * MT && amt_tuning().wide_rb2) return ln ? launch_wide2<2, 1, 4>(p, stream) : launch_wide2<2, 0, 4>(p, stream);
         if (p.K == 512) {
             if (wide_ntw == 7) return ln ? launch_wide<2, 1, 7>(p, stream) : launch_wide<2, 0, 7>(p, stream);
             return ln ? launch_wide<2, 1, 4>(p, stream) : launch_wide<2, 0, 4>(p, stream);
@@ -585,7 +781,8 @@ int32_t amt_launch_decode_gemm(const DecodeGemmParams& p_in, hipStream_t stream)
         return ln ? launch_wide<4, 1, 4>(p, stream) : launch_wide<4, 0, 4>(p, stream);
     }
     // staged rows | folded-FFN vectors | the waves' partial tiles
-    const size_t lds = (size_t)MT * (p.K + XPAD) * sizeof(float) + (p.pro == 1 ? (size_t)2 * p.K * sizeof(float) : 0) + (size_t)NW * 256 * sizeof(float);
+    const size_t lds = (size_t)MT * (p.K + XPAD) * sizeof(float) + (p.pro == 1 ? (size_t)2 * p.K * sizeof(float) : 0) +
+                       (p.pro == 2 ? (size_t)(2 * p.K + 2 * p.K1) * sizeof(float) : 0) + (size_t)NW * 256 * sizeof(float);
     int32_t rc;
     switch (p.K) {
         case 256: rc = launch_variant<1, true>(p, lds, stream); break;

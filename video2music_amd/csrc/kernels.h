@@ -89,8 +89,9 @@ struct AttnDecodeParams {
     float* xn; int ldq, d, new_kv; float eps, q_scale;
     float* k_new; float* v_new;   // the (writable) cache when new_kv
     unsigned long long* stamps;   // diagnostic builds only (-DAMT_STAMPS): [workgroup][8] s_memrealtime stamps; null in the library
-    // rotary embedding of the folded query (new_kv = 0 only): table [positions][rope_dim] of interleaved (cos, sin), the position in
-    // device memory; column n of the d_model-wide query uses entries (n % rope_dim) & ~1 and that + 1 (decode_gemm's rotary epilogue)
+    // rotary embedding of the folded query: table [positions][rope_dim] of interleaved (cos, sin), the position in device memory
+    // (rope_pos; with new_kv = 1 the position is *pos and the new key is rotated too); column n of the d_model-wide query uses
+    // entries (n % rope_dim) & ~1 and that + 1 (decode_gemm's rotary epilogue)
     const float* rope; int rope_dim; const int* rope_pos;
 };
 int32_t amt_launch_attn_decode(const AttnDecodeParams& p, hipStream_t stream);
@@ -120,6 +121,11 @@ struct DecodeGemmParams {
     // (mu, rstd) the statistics of u's row; ln_w / ln_b are that LayerNorm's affine.  The LayerNorm half is also
     // the residual of the columns below n_split.
     int pro; const float* fold_g; const float* fold_c;
+    // pro == 2 (gated FFN-down with LayerNorm folded through the stacked gate | up product, the V1 / V2 plain GLU layers): x holds
+    // the raw UP columns, glu_gate the raw GATE columns (same row stride; both [B][K1]), x2 the pre-LN sum u; with the statistics of
+    // u's row  up = (x - mu*fold_g)*rstd + fold_c,  gate = (glu_gate - mu*fold_g2)*rstd + fold_c2  and the staged row is
+    // [ up * silu(gate) | LayerNorm(u) ]  (GLUExpert.forward, moe.py:44-49, over LayerNorm(u)); K1 % 256 == 0.
+    const float* fold_g2; const float* fold_c2;
     // Column split: output columns [0,n_split) use the packed weight Wp over the first K1 input columns only
     // (bias, residual, ReLU as in mode 0) and go to y; columns [n_split,N) use Wp2 over all K columns, get
     // bias2[n - n_split] only and go to y2[row*ldy2 + n - n_split].  n_split == 0: no split.

@@ -16,7 +16,7 @@
 
 namespace {
 
-constexpr int G_PTRS = 11, L_PTRS = 40;
+constexpr int G_PTRS = 11, L_PTRS = 48;
 enum { G_PR, G_PA, G_WKEY, G_CBIAS, G_ROPE, G_FNW, G_FNB, G_WOUT, G_BOUT, G_SLOT01, G_PE };
 enum { L_SAW, L_SAB, L_SAOW, L_SAOB, L_N1W, L_N1B, L_CAW, L_CAB, L_CAOW, L_CAOB, L_N2W, L_N2B, L_N3W, L_N3B,
        L_KC, L_VC, L_KX, L_VX, L_GATEW, L_GATEB, L_W1, L_B1, L_WG, L_BG, L_W2, L_B2, L_SW1, L_SB1, L_SWG, L_SBG, L_SW2, L_SB2,
@@ -25,7 +25,13 @@ enum { L_SAW, L_SAB, L_SAOW, L_SAOB, L_N1W, L_N1B, L_CAW, L_CAB, L_CAOW, L_CAOB,
        L_GU, L_GUB, L_W2S, L_B2S,
        // lockstep step, norm1 folded through the cross-attention's query projection (null: separate launches): packed
        // [(Wq o gamma) Wo | Wq o gamma] (E x 2E), its bias (Wq o gamma) bo, g = rowsum(Wq o gamma), c = Wq beta + bq
-       L_G1P, L_G1B, L_FQG, L_FQC };
+       L_G1P, L_G1B, L_FQG, L_FQC,
+       // lockstep step of a plain GLU layer, norm2 folded through the stacked gate | up product (the base model's
+       // G2): packed [(Wgu o gamma2) Wo | Wgu o gamma2] (2 dff x 2E), its bias (Wgu o gamma2) bo, g = rowsum(Wgu o gamma2),
+       // c = Wgu beta2 + bgu (gate columns first, then up) -- and norm3 folded through the NEXT layer's QKV projection (the base
+       // model's G3): packed [(Wqkv' o gamma3) W2 | Wqkv' o gamma3] (3E x (dff + E)), bias (Wqkv' o gamma3) b2, g, c; null in the
+       // last layer.  Null entries: the layer takes the separate launches.
+       L_G2P, L_G2B, L_FGUG, L_FGUC, L_G3P, L_G3B, L_FKG, L_FKC };
 
 // (root, attr) either as launch arguments or, for a captured step graph, from device memory (tok[0], tok[1])
 __global__ void embed_one_kernel(int root, int attr, const int* __restrict__ tok, float kv, const float* __restrict__ PR,
@@ -343,6 +349,8 @@ int32_t row_gemm(const RowGemm& r, int B, hipStream_t s) {
 
 // embed: compute the chord-stream rows of this position at the head of the chain (false: the previous call's fused decision left them
 // in ws); advance: increment the position at the tail (false: the fused decision does it)
+static thread_local int g_last_step_launches = 0;     // launches issued by this thread's last lockstep step (introspection for bench.py)
+
 static int32_t v2_step_batch_impl(const void* const* tab, int32_t n_layers, int32_t H, int32_t E, int32_t dff, int32_t n_exp,
                                   int32_t S, int32_t max_seq, int32_t B, const float* keys_dev, int32_t* state_dev,
                                   float* logits_out, float* ws, void* stream, bool embed, bool advance) {
@@ -362,7 +370,10 @@ static int32_t v2_step_batch_impl(const void* const* tab, int32_t n_layers, int3
     float* ffs = Yall + (size_t)(n_exp + 1) * BE;         // 3 * B * (max(n_exp, 1) + 1) * dff expert scratch (gate | up of every expert + shared)
     const int* pos = state_dev;
     int32_t rc;
+    int n_launch = 0;                                   // kernel launches of this call (every helper below issues exactly one)
+    auto CNT = [&](int32_t r) { ++n_launch; return r; };
     if (embed) {
+        ++n_launch;
         hipLaunchKernelGGL(embed_rows_kernel, dim3(B), dim3(128), 0, s, state_dev, B, keys_dev, G(G_PR), G(G_PA), G(G_WKEY), G(G_CBIAS), x, E, G(G_PE));
         AMT_LAUNCH_CHECK();
     }
@@ -372,10 +383,12 @@ static int32_t v2_step_batch_impl(const void* const* tab, int32_t n_layers, int3
     const bool fuse_ln = E <= 1024;
     float* cur = x;
     const float *pend_w = nullptr, *pend_b = nullptr;
+    bool raw_qkv = false;                               // `qkv` holds the raw QKV product of the pending norm3 (folded down projection)
+    const float *raw_g = nullptr, *raw_c = nullptr;
     // finishes a pending norm into `dst` by its own launch (RMSNorm, or nothing to fuse it into)
     auto settle = [&](float* dst) -> int32_t {
         if (!pend_w) return 0;
-        int32_t r2 = norm_rows(cur, nullptr, pend_w, pend_b, dst, B, E, s);
+        int32_t r2 = CNT(norm_rows(cur, nullptr, pend_w, pend_b, dst, B, E, s));
         cur = dst; pend_w = pend_b = nullptr;
         return r2;
     };
@@ -384,16 +397,27 @@ static int32_t v2_step_batch_impl(const void* const* tab, int32_t n_layers, int3
         auto P = [&](int i) { return (const float*)L[i]; };
         float* kc = (float*)L[L_KC]; float* vc = (float*)L[L_VC];                 // [B][H][max_seq][hd]
         // ---- self-attention: [pending LayerNorm ->] QKV projection -> rotary -> q / cache rows, one launch ----
+        if (raw_qkv) {
+            // the previous layer's down projection left qkv_raw = u3 (Wqkv o gamma3)^T: the attention kernel finishes q / k / v with
+            // u3's row statistics, rotates q and k, appends the cache row and publishes norm3(u3) (this layer's residual stream)
+            AttnDecodeParams a{};
+            a.k = kc; a.v = vc; a.k_new = kc; a.v_new = vc; a.o = o; a.B = B; a.H = H; a.hd = hd; a.cap = max_seq; a.pos = pos; a.new_kv = 1;
+            a.q = qkv; a.ldq = 3 * E; a.d = E; a.fold_u = cur; a.fold_g = raw_g; a.fold_c = raw_c; a.fold_lnw = pend_w; a.fold_lnb = pend_b;
+            a.xn = xa; a.eps = 1e-5f; a.q_scale = qscale; a.rope = rope; a.rope_dim = E; a.rope_pos = pos;
+            if ((rc = CNT(amt_launch_attn_decode(a, s)))) return rc;
+            cur = xa; pend_w = pend_b = nullptr; raw_qkv = false;
+        } else {
         if (pend_w && !(fuse_ln && pend_b)) { if ((rc = settle(xa))) return rc; }
         {
             RowGemm r; r.x = cur; r.wp = P(L_SAW); r.b = P(L_SAB); r.y = q; r.N = 3 * E; r.K = E;
             if (pend_w) { r.ln_w = pend_w; r.ln_b = pend_b; r.xn = xa; }
             r.rope = rope; r.rope_cols = 2 * E; r.rope_dim = E; r.pos = pos; r.scale = qscale; r.scale_cols = E;
             r.qkv = true; r.kc = kc; r.vc = vc; r.H = H; r.hd = hd; r.cap = max_seq;
-            if ((rc = row_gemm(r, B, s))) return rc;
+            if ((rc = CNT(row_gemm(r, B, s)))) return rc;
             if (pend_w) { cur = xa; pend_w = pend_b = nullptr; }
         }
-        if ((rc = attn_rows(q, kc, vc, o, B, H, hd, max_seq, 0, pos, s))) return rc;
+        if ((rc = CNT(attn_rows(q, kc, vc, o, B, H, hd, max_seq, 0, pos, s)))) return rc;
+        }
         if (P(L_G1P) && fuse_ln && P(L_N1B)) {
             // u = out-proj + residual AND the raw query product of norm1(u) in one launch; the cross-attention finishes the query
             // (row statistics of u, rotary, scale) in its prologue and publishes norm1(u) as the residual of its out-projection
@@ -401,15 +425,15 @@ static int32_t v2_step_batch_impl(const void* const* tab, int32_t n_layers, int3
             g.B = B; g.eps = 1e-5f; g.scale = 1.f; g.x = o; g.ldx = E; g.x2 = cur; g.ldx2 = E; g.K1 = E; g.K = 2 * E;
             g.Wp = P(L_SAOW); g.bias = P(L_SAOB); g.resid = cur; g.ldr = E; g.y = u; g.ldy = E;
             g.n_split = E; g.N = 2 * E; g.Wp2 = P(L_G1P); g.bias2 = P(L_G1B); g.y2 = q; g.ldy2 = E;
-            if ((rc = amt_launch_decode_gemm(g, s))) return rc;
+            if ((rc = CNT(amt_launch_decode_gemm(g, s)))) return rc;
             AttnDecodeParams a{};
             a.k = P(L_KX); a.v = P(L_VX); a.o = o; a.B = B; a.H = H; a.hd = hd; a.cap = S; a.n_keys = S;
             a.q = q; a.ldq = E; a.d = E; a.fold_u = u; a.fold_g = P(L_FQG); a.fold_c = P(L_FQC); a.fold_lnw = P(L_N1W); a.fold_lnb = P(L_N1B);
             a.xn = xb; a.eps = 1e-5f; a.q_scale = qscale; a.rope = rope; a.rope_dim = E; a.rope_pos = pos;
-            if ((rc = amt_launch_attn_decode(a, s))) return rc;
+            if ((rc = CNT(amt_launch_attn_decode(a, s)))) return rc;
             cur = xb; pend_w = pend_b = nullptr;
         } else {
-        if ((rc = lin_rows(o, P(L_SAOW), P(L_SAOB), cur, u, B, E, E, s))) return rc;           // u = out-proj + residual
+        if ((rc = CNT(lin_rows(o, P(L_SAOW), P(L_SAOB), cur, u, B, E, E, s)))) return rc;           // u = out-proj + residual
         cur = u; pend_w = P(L_N1W); pend_b = P(L_N1B);
         // ---- cross-attention: [norm1 ->] query projection -> rotary, scale ----
         if (!(fuse_ln && pend_b)) { if ((rc = settle(xb))) return rc; }
@@ -417,12 +441,34 @@ static int32_t v2_step_batch_impl(const void* const* tab, int32_t n_layers, int3
             RowGemm r; r.x = cur; r.wp = P(L_CAW); r.b = P(L_CAB); r.y = q; r.N = E; r.K = E;
             if (pend_w) { r.ln_w = pend_w; r.ln_b = pend_b; r.xn = xb; }
             r.rope = rope; r.rope_cols = E; r.rope_dim = E; r.pos = pos; r.scale = qscale; r.scale_cols = E;
-            if ((rc = row_gemm(r, B, s))) return rc;
+            if ((rc = CNT(row_gemm(r, B, s)))) return rc;
             if (pend_w) { cur = xb; pend_w = pend_b = nullptr; }
         }
-        if ((rc = attn_rows(q, P(L_KX), P(L_VX), o, B, H, hd, S, S, nullptr, s))) return rc;      // [B][H][S][hd]
+        if ((rc = CNT(attn_rows(q, P(L_KX), P(L_VX), o, B, H, hd, S, S, nullptr, s)))) return rc;      // [B][H][S][hd]
         }
-        if ((rc = lin_rows(o, P(L_CAOW), P(L_CAOB), cur, y, B, E, E, s))) return rc;
+        if (P(L_G2P) && fuse_ln && P(L_N2B) && !L[L_GATEW]) {
+            // plain GLU layer with norm2 and norm3 folded (5 launches per layer like the base model's chain): the cross-attention's
+            // out-projection also emits the raw stacked gate | up product of the pre-norm sum; the down projection finishes both
+            // halves with that sum's row statistics, applies up * silu(gate), adds norm2(u2) and emits the next layer's raw QKV
+            float* GUr = ffs;                                // [B][2 dff]: raw gate columns, then raw up columns
+            DecodeGemmParams g{};
+            g.B = B; g.eps = 1e-5f; g.scale = 1.f; g.x = o; g.ldx = E; g.x2 = cur; g.ldx2 = E; g.K1 = E; g.K = 2 * E;
+            g.Wp = P(L_CAOW); g.bias = P(L_CAOB); g.resid = cur; g.ldr = E; g.y = y; g.ldy = E;
+            g.n_split = E; g.N = E + 2 * dff; g.Wp2 = P(L_G2P); g.bias2 = P(L_G2B); g.y2 = GUr; g.ldy2 = 2 * dff;
+            if ((rc = CNT(amt_launch_decode_gemm(g, s)))) return rc;
+            DecodeGemmParams d3{};
+            d3.B = B; d3.eps = 1e-5f; d3.scale = 1.f; d3.pro = 2; d3.x = GUr + dff; d3.glu_gate = GUr; d3.ldx = 2 * dff; d3.x2 = y; d3.ldx2 = E;
+            d3.K1 = dff; d3.K = dff + E; d3.fold_g = P(L_FGUG) + dff; d3.fold_c = P(L_FGUC) + dff; d3.fold_g2 = P(L_FGUG); d3.fold_c2 = P(L_FGUC);
+            d3.ln_w = P(L_N2W); d3.ln_b = P(L_N2B); d3.Wp = P(L_W2); d3.bias = P(L_B2); d3.y = u; d3.ldy = E; d3.n_split = E; d3.N = E;
+            if (P(L_G3P) && l + 1 < n_layers) {
+                d3.N = 4 * E; d3.Wp2 = P(L_G3P); d3.bias2 = P(L_G3B); d3.y2 = qkv; d3.ldy2 = 3 * E;
+                raw_qkv = true; raw_g = P(L_FKG); raw_c = P(L_FKC);
+            }
+            if ((rc = CNT(amt_launch_decode_gemm(d3, s)))) return rc;
+            cur = u; pend_w = P(L_N3W); pend_b = P(L_N3B);
+            continue;
+        }
+        if ((rc = CNT(lin_rows(o, P(L_CAOW), P(L_CAOB), cur, y, B, E, E, s)))) return rc;
         cur = y; pend_w = P(L_N2W); pend_b = P(L_N2B);
         // ---- feed-forward: [norm2 ->] gate projection; up projection; down projection with the gate applied in its prologue ----
         if (!(fuse_ln && pend_b)) { if ((rc = settle(xc))) return rc; }
@@ -437,22 +483,32 @@ static int32_t v2_step_batch_impl(const void* const* tab, int32_t n_layers, int3
         {
             RowGemm rg; rg.x = cur; rg.wp = P(L_GU); rg.b = P(L_GUB); rg.y = GU; rg.N = Ngu; rg.K = E;
             if (pend_w) { rg.ln_w = pend_w; rg.ln_b = pend_b; rg.xn = xc; }
-            if ((rc = row_gemm(rg, B, s))) return rc;
+            if ((rc = CNT(row_gemm(rg, B, s)))) return rc;
             if (pend_w) { cur = xc; pend_w = pend_b = nullptr; }
             ffin = cur;
         }
-        if (!L[L_GATEW]) {
+        if (!L[L_GATEW] && P(L_G3P) && fuse_ln && P(L_N3B) && has_up && l + 1 < n_layers) {
+            // u = expert(x) + x AND the next layer's raw QKV product of norm3(u) in one launch (norm3 folded through that projection,
+            // the base model's G3): rows [up * silu(gate) | x], low columns through linear2 over the gated half (+ x), high columns
+            // through [(Wqkv' o gamma3) W2 | Wqkv' o gamma3]; the next self-attention finishes q / k / v with u's row statistics
+            DecodeGemmParams d3{};
+            d3.B = B; d3.eps = 1e-5f; d3.scale = 1.f; d3.x = GU + Nall; d3.glu_gate = GU; d3.ldx = Ngu; d3.x2 = ffin; d3.ldx2 = E;
+            d3.K1 = dff; d3.K = dff + E; d3.Wp = P(L_W2); d3.bias = P(L_B2); d3.resid = ffin; d3.ldr = E; d3.y = u; d3.ldy = E;
+            d3.n_split = E; d3.N = 4 * E; d3.Wp2 = P(L_G3P); d3.bias2 = P(L_G3B); d3.y2 = qkv; d3.ldy2 = 3 * E;
+            if ((rc = CNT(amt_launch_decode_gemm(d3, s)))) return rc;
+            raw_qkv = true; raw_g = P(L_FKG); raw_c = P(L_FKC);
+        } else if (!L[L_GATEW]) {
             RowGemm rd; rd.x = has_up ? GU + Nall : nullptr; rd.gate = GU; rd.ldx = Ngu; rd.wp = P(L_W2); rd.b = P(L_B2); rd.resid = ffin;
             rd.y = u; rd.N = E; rd.K = dff;
-            if ((rc = row_gemm(rd, B, s))) return rc;             // u = expert(x) + x : the pre-norm sum of norm3
+            if ((rc = CNT(row_gemm(rd, B, s)))) return rc;             // u = expert(x) + x : the pre-norm sum of norm3
         } else {
             // the down projections of all experts and the shared one in ONE grouped launch (blockIdx.z = expert)
             RowGemm rd; rd.x = has_up ? GU + Nall : nullptr; rd.gate = GU; rd.ldx = Ngu; rd.wp = P(L_W2S); rd.b = P(L_B2S); rd.y = Yall; rd.N = E; rd.K = dff;
             rd.groups = ng; rd.x_goff = (size_t)dff; rd.y_goff = BE; rd.w_gstride = (size_t)E * dff; rd.b_gstride = E;
-            if ((rc = row_gemm(rd, B, s))) return rc;
+            if ((rc = CNT(row_gemm(rd, B, s)))) return rc;
             const float* shared = L[L_SWG] ? Yall + (size_t)n_exp * BE : nullptr;
             // top-2 routing of every row and the weighted sum of its two experts (+ shared / 2 + residual) in one launch
-            if ((rc = amt_launch_moe_route_combine(ffin, P(L_GATEW), P(L_GATEB), n_exp, Yall, shared, 0.5f, ffin, u, B, E, s))) return rc;
+            if ((rc = CNT(amt_launch_moe_route_combine(ffin, P(L_GATEW), P(L_GATEB), n_exp, Yall, shared, 0.5f, ffin, u, B, E, s)))) return rc;
         }
         cur = u; pend_w = P(L_N3W); pend_b = P(L_N3B);
         // (the next layer's QKV launch consumes `u` before that layer's out-projection writes it again)
@@ -461,21 +517,23 @@ static int32_t v2_step_batch_impl(const void* const* tab, int32_t n_layers, int3
     if (fuse_ln && pend_w && pend_b && G(G_FNB)) {                        // norm3 of the last layer AND decoder.norm in the head's prologue
         RowGemm r; r.x = cur; r.wp = G(G_WOUT); r.b = G(G_BOUT); r.y = logits_out; r.N = 159; r.K = E; r.ln_w = pend_w; r.ln_b = pend_b;
         r.ln2_w = G(G_FNW); r.ln2_b = G(G_FNB);
-        if ((rc = row_gemm(r, B, s))) return rc;
+        if ((rc = CNT(row_gemm(r, B, s)))) return rc;
         pend_w = pend_b = nullptr;
     } else if ((rc = settle(x))) {                                        // norm3 of the last layer
         return rc;
     } else if (fuse_ln && G(G_FNB)) {                                     // decoder.norm in the prologue of the output head
         RowGemm r; r.x = cur; r.wp = G(G_WOUT); r.b = G(G_BOUT); r.y = logits_out; r.N = 159; r.K = E; r.ln_w = G(G_FNW); r.ln_b = G(G_FNB);
-        if ((rc = row_gemm(r, B, s))) return rc;
+        if ((rc = CNT(row_gemm(r, B, s)))) return rc;
     } else {
-        if ((rc = norm_rows(cur, nullptr, G(G_FNW), G(G_FNB), y, B, E, s))) return rc;
-        if ((rc = lin_rows(y, G(G_WOUT), G(G_BOUT), nullptr, logits_out, B, 159, E, s))) return rc;
+        if ((rc = CNT(norm_rows(cur, nullptr, G(G_FNW), G(G_FNB), y, B, E, s)))) return rc;
+        if ((rc = CNT(lin_rows(y, G(G_WOUT), G(G_BOUT), nullptr, logits_out, B, 159, E, s)))) return rc;
     }
     if (advance) {
+        ++n_launch;
         hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, s, state_dev);
         AMT_LAUNCH_CHECK();
     }
+    g_last_step_launches = n_launch;
     return 0;
 }
 
@@ -492,7 +550,10 @@ extern "C" int32_t amt_v2_step_decide_batch(const amt_v2_step_args* st, const am
                                     st->logits_out, st->ws, stream, first != 0, false);
     if (rc) return rc;
     auto G = [&](int i) { return (const float*)st->tab[i]; };
+    g_last_step_launches += 1;                          // + the decision kernel
     return amt_launch_v2_decide_fused(st->logits_out, 159, st->state_dev, dc->tokens, dc->roots, dc->attrs, st->B, dc->T, dc->n_primer, dc->beam,
                                       dc->max_conseq_N, dc->max_conseq_chord, dc->temperature, dc->uniforms, dc->chord_embed, st->keys_dev, G(G_PR),
                                       G(G_PA), G(G_WKEY), G(G_CBIAS), G(G_PE), st->ws, st->E, (hipStream_t)stream);
 }
+
+extern "C" int32_t amt_v2_last_step_launches(void) { return g_last_step_launches; }

@@ -829,7 +829,11 @@ class VideoMusicTransformer_V2(nn.Module):
             a = lyr.cross_attn
             W, b = a.in_proj_weight.detach(), a.in_proj_bias.detach()
             k = ops.linear(rows, W[E:2 * E], b[E:2 * E])
-            if self._rope_cache is not None:                           # per clip: the B = 1 view, positions 0..S-1
+            if self._rope_cache is not None and self._rope_cache.shape[1] * 2 == E:
+                # per clip the B = 1 view, positions 0..S-1 = pair i of the E-wide row at position s rotated by cache[s][i]
+                # (`_attention` does the same for the encoder): one launch for all clips
+                ops.rope(k.view(nb, S, 1, E), self._rope_cache, out=k.view(nb, S, 1, E))
+            elif self._rope_cache is not None:                         # a cache built for another width: clip by clip
                 for c in range(nb):
                     kc_ = k[c * S:(c + 1) * S]
                     ops.rope(kc_.view(H, S, 1, hd), self._rope_cache, out=kc_.view(H, S, 1, hd))
@@ -898,7 +902,8 @@ class VideoMusicTransformer_V2(nn.Module):
                          for _ in st["self"]]
         st["cross_hm"] = [(k.view(nb, S, H, hd).permute(0, 2, 1, 3).contiguous(), v.view(nb, S, H, hd).permute(0, 2, 1, 3).contiguous())
                           for k, v in cross_all]
-        for lyr, (kc, vc), (kx, vx) in zip(self.transformer.decoder.layers, st["self_hm"], st["cross_hm"]):
+        layers = list(self.transformer.decoder.layers)
+        for li, (lyr, (kc, vc), (kx, vx)) in enumerate(zip(layers, st["self_hm"], st["cross_hm"])):
             sa, ca = lyr.self_attn, lyr.cross_attn
             for t in (packed(sa.in_proj_weight), sa.in_proj_bias, packed(sa.out_proj.weight), sa.out_proj.bias, lyr.norm1.weight, nbias(lyr.norm1),
                       packed(ca.in_proj_weight, rows=E), ca.in_proj_bias, packed(ca.out_proj.weight), ca.out_proj.bias, lyr.norm2.weight,
@@ -976,6 +981,52 @@ class VideoMusicTransformer_V2(nn.Module):
                     add(t)
             else:
                 for _ in range(4):
+                    add(None)
+            # A plain GLU layer with norm3 folded through the NEXT layer's QKV projection (the base model's G3, DESIGN.md section 5: the
+            # down projection also emits the raw QKV product, the next self-attention finishes it: 6 launches per layer instead of 7)
+            # and, with AMT_V2_FOLD_FFN=2, norm2 through its stacked gate | up product as well (the base model's G2: 5 launches).
+            #   LayerNorm(u2) Wgu^T + bgu = ((u2 (Wgu o gamma2)^T) - mean g) rstd + c,  u2 (Wgu o gamma2)^T = [o | x] [W' Wo | W']^T + W' bo
+            #   LayerNorm(u3) Wn^T + bn likewise with u3 = h W2^T + b2 + LayerNorm(u2): [h | xn2] [W'' W2 | W'']^T + W'' b2
+            # Widths: whole 256-column chunks on either side of the down projection's staged row [h | xn2] (K = dff + E <= 1536).
+            parts = expert_parts(ff) if isinstance(ff, GLUExpert) else None
+            fold_mode = int(os.environ.get("AMT_V2_FOLD_FFN", "1"))       # 1 (default): norm3 -> next QKV only; 2: norm2 -> gate | up as well; 0: off
+            nxt = layers[li + 1] if li + 1 < len(layers) else None
+            fold_ffn = (fold_mode > 0 and parts is not None and parts["linear1"] is not None
+                        and all(isinstance(n, nn.LayerNorm) for n in (lyr.norm2, lyr.norm3))
+                        and E % 256 == 0 and layer_dff % 256 == 0 and 2 * E <= 1536 and layer_dff + E in (512, 768, 1024, 1536)
+                        and (layer_dff + E < 1536 or E >= 512))
+            if fold_ffn and fold_mode < 2 and nxt is None:
+                fold_ffn = False
+            if fold_ffn:
+                srcs = [ca.out_proj.weight, ca.out_proj.bias, parts["gate"].weight, parts["gate"].bias, parts["linear1"].weight, parts["linear1"].bias,
+                        parts["linear2"].weight, parts["linear2"].bias, lyr.norm2.weight, lyr.norm2.bias, lyr.norm3.weight, lyr.norm3.bias]
+                if nxt is not None:
+                    srcs += [nxt.self_attn.in_proj_weight, nxt.self_attn.in_proj_bias]
+
+                def build_ffn_fold(ca=ca, lyr=lyr, parts=parts, nxt=nxt, mode=fold_mode):
+                    row = lambda v: v.detach().view(1, -1).contiguous()
+                    out = [None] * 4
+                    if mode >= 2:         # measured slower than the separate launches at d_model 512 (profiles/r03_v2_fold_ab.json): kept for A/B
+                        Wo, bo = ca.out_proj.weight.detach(), ca.out_proj.bias.detach()
+                        Wgu = torch.cat([parts["gate"].weight.detach(), parts["linear1"].weight.detach()]).contiguous()     # (2 dff, E): gate rows first
+                        bgu = torch.cat([parts["gate"].bias.detach(), parts["linear1"].bias.detach()])
+                        Wp = (Wgu * lyr.norm2.weight.detach().unsqueeze(0)).contiguous()                                   # Wgu o gamma2
+                        P2 = torch.cat([ops.linear(Wp, Wo.t().contiguous()), Wp], dim=1).contiguous()                     # (2 dff, 2E), a temporary
+                        out = [pack_now(P2), ops.linear(row(bo), Wp).view(-1).contiguous(), Wp.sum(dim=1).contiguous(),
+                               (ops.linear(row(lyr.norm2.bias), Wgu).view(-1) + bgu).contiguous()]
+                    if nxt is None:
+                        return out + [None] * 4
+                    Wn, bn = nxt.self_attn.in_proj_weight.detach(), nxt.self_attn.in_proj_bias.detach()
+                    W2, b2 = parts["linear2"].weight.detach(), parts["linear2"].bias.detach()                         # (E, dff)
+                    Wq = (Wn * lyr.norm3.weight.detach().unsqueeze(0)).contiguous()                                    # Wqkv' o gamma3
+                    P3 = torch.cat([ops.linear(Wq, W2.t().contiguous()), Wq], dim=1).contiguous()                      # (3E, dff + E)
+                    return out + [pack_now(P3), ops.linear(row(b2), Wq).view(-1).contiguous(), Wq.sum(dim=1).contiguous(),
+                                  (ops.linear(row(lyr.norm3.bias), Wn.contiguous()).view(-1) + bn).contiguous()]
+
+                for t in cached(tuple(t.data_ptr() for t in srcs) + ("ffnfold", fold_mode), tuple(t._version for t in srcs), build_ffn_fold):
+                    add(t)
+            else:
+                for _ in range(8):
                     add(None)
             widths.add(layer_dff)
             dff = layer_dff
