@@ -291,6 +291,22 @@ int32_t amt_glu_expert_fwd(const float* x, const float* w1, const float* b1, con
                            int32_t n, int32_t d, int32_t dff, void* stream);
 int32_t amt_moe_combine_fwd(const float* y_rows, const int32_t* slot_pos, const int32_t* idx, const float* wts,
                             const float* shared, float shared_scale, float* out, int32_t n_tok, int32_t d, void* stream);
+/* Expert-parallel execution with the plans on the DEVICE (video2music_amd/model/moe.py:expert_parallel_moe):
+ * amt_moe_ep_dispatch_plan_fwd: from one rank's routing idx[2*n_tok] the rows per expert counts_out[n_exp], the send-buffer order
+ *   perm[2*n_tok] (send row -> token; ordered by expert, exact packing, so the rows of one destination rank are contiguous) and
+ *   slot_pos[2*n_tok] (assignment token*2+slot -> send row: what amt_moe_combine_fwd takes).  ints: >= 256 int32 of scratch, zero
+ *   before the first call.
+ * amt_gather_rows_fwd: dst[i] = src[index[i]] (a negative index gives a zero row): the send buffer x[perm].
+ * amt_moe_ep_expert_fwd: the rank's e_local experts (stacked tensors as amt_moe_fwd takes them) on the n_recv rows the all_to_all
+ *   delivered, grouped by (source rank, local expert) with the segment sizes in DEVICE memory recv_counts[world][e_local]; results
+ *   y_out[n_recv][d] in arrival order.  One grouped GEMM launch per projection; scratch: amt_moe_ep_expert_scratch_floats. */
+int32_t amt_moe_ep_dispatch_plan_fwd(const int32_t* idx, int32_t n_tok, int32_t n_exp, int32_t* counts_out, int32_t* perm,
+                                     int32_t* slot_pos, int32_t* ints, void* stream);
+int32_t amt_gather_rows_fwd(const float* src, const int32_t* index, float* dst, int32_t n_rows, int32_t d, void* stream);
+int64_t amt_moe_ep_expert_scratch_floats(int32_t n_recv, int32_t d, int32_t dff, int32_t e_local);
+int32_t amt_moe_ep_expert_fwd(const float* rows, const int32_t* recv_counts, int32_t world, int32_t e_local, int32_t n_recv,
+                              const float* w1, const float* b1, const float* wg, const float* bg, const float* w2, const float* b2,
+                              float* y_out, float* scratch, int32_t d, int32_t dff, void* stream);
 
 /* ---- VideoMusicTransformer_V2 '2.2': one KV-cached decode step of one clip ------------------------
  * Issues, from one call, the launch sequence of the decoder restricted to position t (reference

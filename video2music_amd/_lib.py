@@ -94,6 +94,10 @@ SIGNATURES = {
     "amt_moe_route_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "amt_glu_expert_fwd": [_P] * 9 + [_I, _I, _I, _P],
     "amt_moe_combine_fwd": [_P, _P, _P, _P, _P, _F, _P, _I, _I, _P],
+    "amt_moe_ep_dispatch_plan_fwd": [_P, _I, _I, _P, _P, _P, _P, _P],
+    "amt_gather_rows_fwd": [_P, _P, _P, _I, _I, _P],
+    "amt_moe_ep_expert_scratch_floats": [_I, _I, _I, _I],
+    "amt_moe_ep_expert_fwd": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "amt_dwconv1d_silu_fwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "amt_selective_scan_fwd": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "amt_concat2_fwd": [_P, _I, _P, _I, _P, _I, _I, _P],
@@ -108,7 +112,7 @@ SIGNATURES = {
     "amt_v2_step_batch": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
 }
 _RESTYPES = {"amt_last_error": C.c_char_p, "amt_decode_step_bytes": C.c_int64, "amt_moe_scratch_floats": C.c_int64, "amt_moe_topk_scratch_floats": C.c_int64,
-             "amt_v2_step_ws_floats": C.c_int64, "amt_v2_step_batch_ws_floats": C.c_int64}
+             "amt_v2_step_ws_floats": C.c_int64, "amt_v2_step_batch_ws_floats": C.c_int64, "amt_moe_ep_expert_scratch_floats": C.c_int64}
 _NO_STATUS = set(_RESTYPES) | {"amt_abi_version", "amt_v2_last_step_launches"}
 
 ABI_VERSION = 2          # AMT_ABI_VERSION of include/amt_hip.h these prototypes were written against

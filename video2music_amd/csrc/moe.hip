@@ -260,6 +260,77 @@ __global__ __launch_bounds__(128) void moe_route_combine_kernel(const float* __r
 
 inline size_t align4(size_t n) { return (n + 3) / 4 * 4; }
 
+
+// ---- expert-parallel execution: plans built on the device ----
+// Dispatch side: exact (un-padded) segment starts per expert, so that the rows of one destination rank are contiguous in the
+// send buffer and the buffer is what all_to_all_single takes.  counts[0..63] in; offsets[0..64], counts_out[0..n_exp) out;
+// cursors zeroed, counts re-zeroed for the next call.
+__global__ __launch_bounds__(64) void moe_ep_offsets_kernel(int* __restrict__ counts, int* __restrict__ offsets, int* __restrict__ cursors,
+                                                            int* __restrict__ counts_out, int n_exp) {
+    __shared__ int cnt[64];
+    const int tid = threadIdx.x;
+    cnt[tid] = tid < n_exp ? counts[tid] : 0;
+    __syncthreads();
+    if (tid == 0) {
+        int o = 0;
+        for (int e = 0; e < n_exp; ++e) { offsets[e] = o; o += cnt[e]; }
+        offsets[n_exp] = o;
+    }
+    if (tid < n_exp) counts_out[tid] = cnt[tid];
+    cursors[tid] = 0;
+    counts[tid] = 0;
+}
+
+// dst[i] = src[index[i]]  (index < 0: a row of zeros); one wave per row, float4 lanes
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ index, float* __restrict__ dst,
+                                                          int n_rows, int d) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n_rows) return;
+    const int from = index[row];
+    for (int c = lane * 4; c < d; c += 256) {
+        const float4 v = from >= 0 ? ld4(src + (size_t)from * d + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        st4(dst + (size_t)row * d + c, v);
+    }
+}
+
+// Expert side: the received rows arrive grouped by (source rank, local expert): segment (s, j) has recv_counts[s * e_local + j]
+// rows.  The grouped GEMMs want the rows of one local expert in one TILE-aligned run: perm[slot] = arrival row (or -1 in the
+// padding), slot_of[arrival row] = slot, tile_group[tile] = local expert (or -1).  One workgroup (world * e_local <= 64 segments).
+__global__ __launch_bounds__(1024) void moe_ep_expert_plan_kernel(const int* __restrict__ recv_counts, int world, int e_local, int n_recv, int Mp,
+                                                                  int* __restrict__ perm, int* __restrict__ slot_of, int* __restrict__ tile_group) {
+    __shared__ int seg_src[64], seg_dst[64], seg_n[64], off[65], cnt[64];
+    const int tid = threadIdx.x, nseg = world * e_local;
+    if (tid == 0) {
+        for (int j = 0; j < e_local; ++j) { cnt[j] = 0; for (int s2 = 0; s2 < world; ++s2) cnt[j] += recv_counts[s2 * e_local + j]; }
+        int o = 0;
+        for (int j = 0; j < e_local; ++j) { off[j] = o; o += (cnt[j] + TILE - 1) / TILE * TILE; }
+        off[e_local] = o;
+        int src = 0;
+        for (int s2 = 0; s2 < world; ++s2)
+            for (int j = 0; j < e_local; ++j) {
+                const int n = recv_counts[s2 * e_local + j];
+                int before = 0;
+                for (int s3 = 0; s3 < s2; ++s3) before += recv_counts[s3 * e_local + j];
+                seg_src[s2 * e_local + j] = src; seg_dst[s2 * e_local + j] = off[j] + before; seg_n[s2 * e_local + j] = n;
+                src += n;
+            }
+    }
+    __syncthreads();
+    for (int i = tid; i < Mp; i += 1024) perm[i] = -1;
+    for (int t = tid; t < Mp / TILE; t += 1024) {
+        int g = -1;
+        for (int j = 0; j < e_local; ++j)
+            if (t * TILE >= off[j] && t * TILE < off[j] + cnt[j]) g = j;
+        tile_group[t] = g;
+    }
+    __syncthreads();
+    for (int sg = 0; sg < nseg; ++sg)
+        for (int i = tid; i < seg_n[sg]; i += 1024) {
+            const int r = seg_src[sg] + i, slot = seg_dst[sg] + i;
+            if (r < n_recv) { perm[slot] = r; slot_of[r] = slot; }
+        }
+}
+
 }  // namespace
 
 extern "C" int64_t amt_moe_topk_scratch_floats(int32_t n_tok, int32_t d, int32_t dff, int32_t n_exp, int32_t k) {
@@ -412,6 +483,74 @@ extern "C" int32_t amt_moe_combine_fwd(const float* y_rows, const int32_t* slot_
                                        const float* shared, float shared_scale, float* out, int32_t n_tok, int32_t d, void* stream) {
     AMT_CHECK_ARG(y_rows && slot_pos && idx && wts && out && n_tok > 0 && d % 4 == 0, "amt_moe_combine_fwd: bad argument");
     hipLaunchKernelGGL(moe_combine_kernel, dim3(n_tok), dim3(128), 0, (hipStream_t)stream, y_rows, slot_pos, idx, wts, shared, shared_scale, out, d);
+    AMT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- expert-parallel pieces, device side (the host only learns the split sizes) ----
+// Dispatch plan of one rank's routed (token, slot) assignments idx[2 * n_tok]: counts_out[n_exp] rows per expert, perm[2 * n_tok]
+// (send-buffer row -> token) and slot_pos[2 * n_tok] (assignment -> send-buffer row); the send buffer is ordered by expert, exact
+// packing.  ints: >= 256 words of scratch, zero before the first call (the plan leaves them zero again).
+extern "C" int32_t amt_moe_ep_dispatch_plan_fwd(const int32_t* idx, int32_t n_tok, int32_t n_exp, int32_t* counts_out, int32_t* perm,
+                                                int32_t* slot_pos, int32_t* ints, void* stream) {
+    AMT_CHECK_ARG(idx && counts_out && perm && slot_pos && ints && n_tok > 0 && n_exp >= 2 && n_exp <= 64, "amt_moe_ep_dispatch_plan_fwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int n_assign = 2 * n_tok;
+    hipLaunchKernelGGL(moe_count_kernel, dim3(cdiv(n_assign, 256)), dim3(256), 0, s, idx, n_assign, ints);
+    hipLaunchKernelGGL(moe_ep_offsets_kernel, dim3(1), dim3(64), 0, s, ints, ints + 64, ints + 192, counts_out, n_exp);
+    hipLaunchKernelGGL(moe_place_kernel, dim3(cdiv(n_assign, 256)), dim3(256), 0, s, idx, n_assign, ints + 64, ints + 192, perm, slot_pos, 2);
+    AMT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int32_t amt_gather_rows_fwd(const float* src, const int32_t* index, float* dst, int32_t n_rows, int32_t d, void* stream) {
+    AMT_CHECK_ARG(src && index && dst && n_rows >= 0 && d % 4 == 0, "amt_gather_rows_fwd: bad argument");
+    if (n_rows == 0) return 0;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(n_rows, 4)), dim3(256), 0, (hipStream_t)stream, src, index, dst, n_rows, d);
+    AMT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int64_t amt_moe_ep_expert_scratch_floats(int32_t n_recv, int32_t d, int32_t dff, int32_t e_local) {
+    const size_t Mp = ((size_t)n_recv + TILE - 1) / TILE * TILE + (size_t)TILE * e_local;
+    return (int64_t)(2 * Mp * dff + Mp * d + align4(Mp) + align4((size_t)n_recv + 1) + align4(Mp / TILE + 1) + 64);
+}
+
+// The local experts of one rank on the rows it received: rows [n_recv][d] grouped by (source rank, local expert) as the
+// all_to_all delivers them, recv_counts (DEVICE, [world][e_local]) the segment sizes; w1 .. b2 the stacked tensors of the rank's
+// e_local experts (as amt_moe_fwd takes them; w1 null: Linear -> SiLU -> Linear experts).  y_out [n_recv][d] in ARRIVAL order
+// (what the return all_to_all sends back).  One grouped launch per projection (moe.py:36-49 per expert).
+extern "C" int32_t amt_moe_ep_expert_fwd(const float* rows, const int32_t* recv_counts, int32_t world, int32_t e_local, int32_t n_recv,
+                                         const float* w1, const float* b1, const float* wg, const float* bg, const float* w2, const float* b2,
+                                         float* y_out, float* scratch, int32_t d, int32_t dff, void* stream) {
+    AMT_CHECK_ARG(rows && recv_counts && wg && w2 && y_out && scratch, "amt_moe_ep_expert_fwd: null pointer");
+    AMT_CHECK_ARG(world >= 1 && e_local >= 1 && world * e_local <= 64 && n_recv >= 0 && d % 32 == 0 && dff % 32 == 0, "amt_moe_ep_expert_fwd: bad shape");
+    if (n_recv == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int Mp = (n_recv + TILE - 1) / TILE * TILE + TILE * e_local;
+    float* G = scratch;
+    float* Hh = G + (size_t)Mp * dff;
+    float* Y = Hh + (size_t)Mp * dff;
+    int* perm = (int*)(Y + (size_t)Mp * d);
+    int* slot_of = perm + align4(Mp);
+    int* tile_group = slot_of + align4((size_t)n_recv + 1);
+    hipLaunchKernelGGL(moe_ep_expert_plan_kernel, dim3(1), dim3(1024), 0, s, recv_counts, world, e_local, n_recv, Mp, perm, slot_of, tile_group);
+    AMT_LAUNCH_CHECK();
+    int32_t rc;
+    GemmParams g = gemm_params(rows, d, wg, d, w1 ? G : Hh, dff, Mp, dff, d, bg);
+    g.a_gather = perm; g.tile_group = tile_group; g.w_group_stride = (size_t)dff * d; g.bias_group_stride = dff;
+    g.relu = w1 ? 0 : 2;
+    if ((rc = amt_launch_gemm(g, s))) return rc;
+    if (w1) {
+        GemmParams u = gemm_params(rows, d, w1, d, Hh, dff, Mp, dff, d, b1);
+        u.a_gather = perm; u.tile_group = tile_group; u.w_group_stride = (size_t)dff * d; u.bias_group_stride = dff;
+        u.silu_mul = G; u.ld_silu = dff;
+        if ((rc = amt_launch_gemm(u, s))) return rc;
+    }
+    GemmParams dn = gemm_params(Hh, dff, w2, dff, Y, d, Mp, d, dff, b2);
+    dn.tile_group = tile_group; dn.w_group_stride = (size_t)d * dff; dn.bias_group_stride = d;
+    if ((rc = amt_launch_gemm(dn, s))) return rc;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(n_recv, 4)), dim3(256), 0, s, Y, slot_of, y_out, n_recv, d);
     AMT_LAUNCH_CHECK();
     return 0;
 }

@@ -16,54 +16,151 @@ import torch.nn as nn
 from .. import _lib
 
 
-def expert_parallel_moe(x, idx, wts, n_experts, run_local_experts, combine, group=None):
+class _Phases:
+    """Optional wall-clock phases of one expert-parallel layer call (tools/bench_moe_ep.py): each mark synchronises the device,
+    so a timed call is slower than an untimed one; `None` costs nothing."""
+
+    def __init__(self, device):
+        import time
+        self.t, self.dev, self.ms, self.clock = None, device, {}, time.perf_counter
+
+    def mark(self, name):
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)
+        now = self.clock()
+        if self.t is not None:
+            self.ms[name] = self.ms.get(name, 0.0) + 1e3 * (now - self.t)
+        self.t = now
+
+
+def expert_parallel_moe(x, idx, ops, n_experts, group=None, phases=None):
     """Expert-parallel top-2 MoE over ``torch.distributed`` (experts placed per GPU).
 
-    Rank r owns experts ``[r*E/W, (r+1)*E/W)``.  Every rank routes its own tokens (``idx``/``wts`` (n_tok,2)),
-    sends each (token, slot) row to the owner of its expert with ONE ``all_to_all_single`` (rows sorted by
-    expert, so per-rank segments are contiguous), runs its experts on what it received, returns the
-    results with a second ``all_to_all_single`` and combines per token in expert-index order.
+    Rank r owns experts ``[r*E/W, (r+1)*E/W)``.  Every rank routes its own tokens (``idx`` (n_tok, 2) int32), sends each
+    (token, slot) row to the owner of its expert with ONE ``all_to_all_single`` (the send buffer is ordered by expert, so the
+    per-rank segments are contiguous), runs its experts on what it received, returns the results with a second
+    ``all_to_all_single`` and combines per token in expert-index order.
 
-    ``run_local_experts(rows, counts_per_local_expert) -> rows`` and ``combine(y_sorted, slot_pos) -> out``
-    are supplied by the caller (HIP kernels in production, the CPU oracle in the gloo test).
+    Everything that touches rows runs on the device through ``ops`` (HIP kernels in production -- ``_HipEpOps`` below: the plan
+    kernels of the local layer, a row gather, ONE grouped expert launch per projection --, torch on the CPU in the gloo test):
+
+        ops.plan(idx, counts_out)            -> perm (2 n_tok,), slot_pos (2 n_tok,) [send row -> token; assignment -> send row]; rows per expert into counts_out (E,) int32
+        ops.gather(x, perm)                  -> send rows (2 n_tok, d)
+        ops.overlap()                        -> anything independent of the exchange (the shared expert); runs while rows travel
+        ops.experts(rows, recv_counts, n)    -> results (n, d) in arrival order; recv_counts (W, E/W) int32 on the rows' device
+        ops.combine(y_sorted, slot_pos)      -> (n_tok, d)
+
+    The host learns ONE thing per call, in ONE synchronisation: the split sizes (rows per destination / source rank), which the
+    variable-size collective needs as Python ints.  The per-expert counts are exchanged on the device first (a (W, E/W) int32
+    all_to_all) and both count matrices come to the host together.
     """
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     assert n_experts % world == 0, "experts must divide evenly over ranks"
     e_local = n_experts // world
     n_tok, d = x.shape
-    flat_e = idx.reshape(-1).long()
-    order = torch.argsort(flat_e, stable=True)                     # sorted (token, slot) assignments
-    send_rows = x.index_select(0, order // 2).contiguous()
-    counts = torch.bincount(flat_e, minlength=n_experts)            # rows per expert on this rank
-    send_counts = counts.view(world, e_local).cpu()
-    # 1) sizes: who sends how many rows for which of my experts
-    recv_counts = torch.empty_like(send_counts)
-    cpu_group_ok = dist.get_backend(group) == "gloo"
-    sc_dev = send_counts if cpu_group_ok else send_counts.to(x.device)
-    rc_dev = recv_counts if cpu_group_ok else recv_counts.to(x.device)
-    dist.all_to_all_single(rc_dev, sc_dev, group=group)
-    recv_counts = rc_dev.cpu()
-    in_splits = recv_counts.sum(1).tolist()
-    out_splits = send_counts.sum(1).tolist()
-    # 2) rows to their experts' owners
-    stage = (lambda t: t.cpu()) if (cpu_group_ok and x.is_cuda) else (lambda t: t)
-    recv_rows = torch.empty(sum(in_splits), d, dtype=x.dtype, device="cpu" if (cpu_group_ok and x.is_cuda) else x.device)
-    dist.all_to_all_single(recv_rows, stage(send_rows), output_split_sizes=in_splits, input_split_sizes=out_splits, group=group)
-    recv_rows = recv_rows.to(x.device)
-    # received rows are grouped by source rank, inside a source by local expert: regroup by local expert
-    src_e = torch.repeat_interleave(torch.arange(world * e_local) % e_local, recv_counts.reshape(-1)).to(x.device)
-    by_e = torch.argsort(src_e, stable=True)
-    per_local = recv_counts.sum(0).tolist()
-    y_local = run_local_experts(recv_rows.index_select(0, by_e).contiguous(), per_local)
-    y_recv = torch.empty_like(y_local)
-    y_recv[by_e] = y_local                                          # back to arrival order
-    # 3) results back to the token owners
-    y_sorted = torch.empty(send_rows.shape[0], d, dtype=x.dtype, device="cpu" if (cpu_group_ok and x.is_cuda) else x.device)
-    dist.all_to_all_single(y_sorted, stage(y_recv.contiguous()), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
-    y_sorted = y_sorted.to(x.device)
-    slot_pos = torch.empty_like(order)
-    slot_pos[order] = torch.arange(order.numel(), device=order.device)   # row of assignment (token*2+slot) in y_sorted
-    return combine(y_sorted, slot_pos.to(torch.int32).view(n_tok, 2))
+    # gloo moves host tensors: the rehearsal path (two ranks on one GPU, CPU tests) stages through the host
+    via_host = dist.get_backend(group) == "gloo" and x.is_cuda
+    stage = (lambda t: t.cpu()) if via_host else (lambda t: t)
+    unstage = (lambda t: t.to(x.device)) if via_host else (lambda t: t)
+    # both count matrices in ONE buffer: [0] rows per (destination rank, its local expert) from the plan, [1] what the peers send here
+    both_dev = torch.empty(2, world, e_local, dtype=torch.int32, device=x.device)
+    perm, slot_pos = ops.plan(idx, both_dev[0].view(-1))
+    send_rows = ops.gather(x, perm)
+    if phases: phases.mark("route_plan_gather")
+    # 1) sizes: exchanged where the rows live, then ONE copy to the host
+    if via_host:
+        sc_h = both_dev[0].cpu()
+        rc_h = torch.empty_like(sc_h)
+        dist.all_to_all_single(rc_h, sc_h, group=group)
+        both_dev[1].copy_(rc_h)
+        both = torch.stack([sc_h, rc_h])
+    else:
+        dist.all_to_all_single(both_dev[1], both_dev[0], group=group)
+        both = both_dev.cpu()                                         # the one host synchronisation of the call
+    recv_counts = both_dev[1]
+    out_splits, in_splits = both[0].sum(1).tolist(), both[1].sum(1).tolist()
+    n_recv = sum(in_splits)
+    if phases: phases.mark("counts_exchange_and_host_sync")
+    # 2) rows to their experts' owners; whatever does not depend on them runs meanwhile
+    recv_rows = torch.empty(n_recv, d, dtype=x.dtype, device="cpu" if via_host else x.device)
+    work = dist.all_to_all_single(recv_rows, stage(send_rows), output_split_sizes=in_splits, input_split_sizes=out_splits, group=group,
+                                  async_op=True)
+    ops.overlap()
+    work.wait()
+    recv_rows = unstage(recv_rows)
+    if phases: phases.mark("dispatch_all_to_all")
+    y_recv = ops.experts(recv_rows, recv_counts, n_recv)
+    if phases: phases.mark("local_experts")
+    # 3) results back to the token owners, landing at the rows they were sent from
+    y_sorted = torch.empty(2 * n_tok, d, dtype=x.dtype, device="cpu" if via_host else x.device)
+    dist.all_to_all_single(y_sorted, stage(y_recv), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+    y_sorted = unstage(y_sorted)
+    if phases: phases.mark("return_all_to_all")
+    out = ops.combine(y_sorted, slot_pos)
+    if phases:
+        phases.mark("combine")
+        phases.bytes_per_all_to_all = {"sent": int(sum(out_splits)) * d * 4, "received": int(n_recv) * d * 4,
+                                       "leaving_this_rank": int(sum(out_splits) - out_splits[rank]) * d * 4}
+    return out
+
+
+class _HipEpOps:
+    """`expert_parallel_moe`'s row operations on the library's kernels (no torch indexing kernels in the layer)."""
+
+    def __init__(self, layer, xf, idx, wts, rank, e_local):
+        self.layer, self.xf, self.idx, self.wts, self.rank, self.e_local = layer, xf, idx, wts, rank, e_local
+        self.n_tok, self.d = xf.shape
+        self.dff = expert_dff(layer.experts[0])
+        self.shared = None
+        if getattr(layer, "_ep_ints", None) is None or layer._ep_ints.device != xf.device:
+            layer._ep_ints = torch.zeros(256, dtype=torch.int32, device=xf.device)      # plan scratch: zero between calls
+
+    def plan(self, idx, counts):
+        n, dev = self.n_tok, self.xf.device
+        perm = torch.empty(2 * n, dtype=torch.int32, device=dev)
+        slot_pos = torch.empty(2 * n, dtype=torch.int32, device=dev)
+        p = _lib.ptr
+        _lib.call("amt_moe_ep_dispatch_plan_fwd", p(idx), n, self.layer.n_experts, p(counts), p(perm), p(slot_pos), p(self.layer._ep_ints),
+                  _lib.stream_ptr())
+        return perm, slot_pos
+
+    def gather(self, x, perm):
+        rows = torch.empty(perm.numel(), self.d, device=x.device, dtype=torch.float32)
+        _lib.call("amt_gather_rows_fwd", _lib.ptr(x), _lib.ptr(perm), _lib.ptr(rows), perm.numel(), self.d, _lib.stream_ptr())
+        return rows
+
+    def _glu(self, rows, m):
+        out = torch.empty(rows.shape[0], self.d, device=rows.device, dtype=torch.float32)
+        scratch = torch.empty(2 * rows.shape[0] * self.dff, device=rows.device, dtype=torch.float32)
+        p = _lib.ptr
+        _lib.call("amt_glu_expert_fwd", p(rows), *[p(v) for v in expert_tensors(m)], p(out), p(scratch), rows.shape[0], self.d, self.dff,
+                  _lib.stream_ptr())
+        return out
+
+    def overlap(self):
+        if self.layer.shared:
+            self.shared = self._glu(self.xf, self.layer.shared_expert)
+
+    def experts(self, rows, recv_counts, n_recv):
+        y = torch.empty(n_recv, self.d, device=rows.device, dtype=torch.float32)
+        if n_recv == 0:
+            return y
+        lo = self.rank * self.e_local
+        w = [None if t is None else t[lo:lo + self.e_local].contiguous() for t in self.layer._stacked_expert_weights()]
+        world = recv_counts.shape[0]
+        scratch = torch.empty(_lib.call("amt_moe_ep_expert_scratch_floats", n_recv, self.d, self.dff, self.e_local), device=rows.device,
+                              dtype=torch.float32)
+        p = _lib.ptr
+        _lib.call("amt_moe_ep_expert_fwd", p(rows.contiguous()), p(recv_counts.contiguous()), world, self.e_local, n_recv, *[p(t) for t in w], p(y),
+                  p(scratch), self.d, self.dff, _lib.stream_ptr())
+        return y
+
+    def combine(self, y_sorted, slot_pos):
+        out = torch.empty(self.n_tok, self.d, device=self.xf.device, dtype=torch.float32)
+        p = _lib.ptr
+        _lib.call("amt_moe_combine_fwd", p(y_sorted.contiguous()), p(slot_pos), p(self.idx), p(self.wts), p(self.shared),
+                  1.0 / self.layer.n_experts_per_token, p(out), self.n_tok, self.d, _lib.stream_ptr())
+        return out
 
 
 class GLUExpert(nn.Module):
@@ -176,12 +273,12 @@ class _MoEBase(nn.Module):
         self.expert_parallel, self.ep_group = True, group
         return self
 
-    def _run_ep(self, x):
+    def _run_ep(self, x, phases=None):
         L, B, d = x.shape
         n_tok, n_exp = L * B, self.n_experts
-        dff = expert_dff(self.experts[0])
         xf = x.to(torch.float32).contiguous().view(n_tok, d)
         p, st = _lib.ptr, _lib.stream_ptr
+        if phases: phases.mark("start")
         idx = torch.empty(n_tok, 2, device=x.device, dtype=torch.int32)
         wts = torch.empty(n_tok, 2, device=x.device, dtype=torch.float32)
         gw, gb = self.gate.weight.detach().contiguous(), self.gate.bias.detach().contiguous()
@@ -190,33 +287,8 @@ class _MoEBase(nn.Module):
             gw, gb = (gw / t).contiguous(), (gb / t).contiguous()
         _lib.call("amt_moe_route_fwd", p(xf), p(gw), p(gb), p(idx), p(wts), n_tok, d, n_exp, st())
         world, rank = dist.get_world_size(self.ep_group), dist.get_rank(self.ep_group)
-        e_local = n_exp // world
-
-        def glu(rows, e):
-            m = self.experts[e] if e is not None else self.shared_expert
-            out = torch.empty(rows.shape[0], d, device=rows.device, dtype=torch.float32)
-            if rows.shape[0] == 0:
-                return out
-            scratch = torch.empty(2 * rows.shape[0] * dff, device=rows.device, dtype=torch.float32)
-            t = expert_tensors(m)
-            _lib.call("amt_glu_expert_fwd", p(rows), *[p(v) for v in t], p(out), p(scratch), rows.shape[0], d, dff, st())
-            return out
-
-        def run_local(rows, per_local):
-            outs, o = [], 0
-            for j, n in enumerate(per_local):
-                outs.append(glu(rows[o:o + n].contiguous(), rank * e_local + j))
-                o += n
-            return torch.cat(outs) if outs else rows
-
-        def combine(y_sorted, slot_pos):
-            out = torch.empty(n_tok, d, device=x.device, dtype=torch.float32)
-            shared = glu(xf, None) if self.shared else None
-            _lib.call("amt_moe_combine_fwd", p(y_sorted.contiguous()), p(slot_pos.contiguous()), p(idx), p(wts), p(shared),
-                      1.0 / self.n_experts_per_token, p(out), n_tok, d, st())
-            return out
-
-        out = expert_parallel_moe(xf, idx, wts, n_exp, run_local, combine, self.ep_group)
+        ops = _HipEpOps(self, xf, idx, wts, rank, n_exp // world)
+        out = expert_parallel_moe(xf, idx, ops, n_exp, self.ep_group, phases)
         self.last_routing = (idx.view(L, B, 2), wts.view(L, B, 2))
         return out.view(L, B, d)
 
