@@ -181,22 +181,39 @@ def _sha256(path):
         return hashlib.sha256(fh.read()).hexdigest()
 
 
-def pmc_traffic(kind, algorithmic_bytes_per_launch, shape_ok=True):
-    """HBM bytes per launch of the decode attention from the committed PMC pass (FETCH_SIZE doubled per the gfx950 correction +
-    WRITE_SIZE, collected by tools/pmc_attn.py under rocprofv3 --pmc in separate passes) scaled to this run's algorithmic bytes.
-    Counters cannot be read from inside bench.py, so the figure is only reported while the kernel source is byte-identical to
-    the one the pass was collected on (sha256 recorded in the profile); otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_attn_traffic.json")
-    src = os.path.join(ROOT, "video2music_amd", "csrc", "attn_decode.hip")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc_decode_step.json")
+PMC_KERNELS = {            # kind -> (source file whose sha gates the figure, kernel-name test)
+    "self_attn": ("attn_decode.hip", lambda k: k.startswith("attn_decode_kernel<64, true")),
+    "cross_attn": ("attn_decode.hip", lambda k: k.startswith("attn_decode_kernel<64, false")),
+    "decode_gemm": ("decode_gemm.hip", lambda k: k.startswith("decode_gemm_kernel<")),
+}
+
+
+def pmc_traffic(kind, shape_ok=True, algorithmic_bytes=None):
+    """HBM-side bytes per launch of a decode-step kernel class from the committed PMC passes (tools/gpu_pmc_step.sh: rocprofv3 --pmc
+    FETCH_SIZE and --pmc WRITE_SIZE in separate passes -- the skinny GEMMs inside the real captured step, the attention kernels
+    through tools/pmc_attn.py over the positions of a T = 1024 generate; FETCH_SIZE doubled per the gfx950 correction of
+    MI355X_MICROARCH.md; launch-weighted mean over the kernel's variants).
+    Counters cannot be read from inside bench.py, so the figure is reported only while the kernel's source file is byte-identical
+    to the one the passes were collected on (sha256 recorded in the profile) and this run has the profile's shape; otherwise null."""
+    src_name, match = PMC_KERNELS[kind]
     if not shape_ok:
-        return None, "the committed PMC pass was collected at config 2's launch shape (B=32, H=8, hd=64) only"
-    if not (os.path.exists(path) and os.path.exists(src)):
+        return None, "the committed PMC passes were collected at config 2's shape (32 clips, T = 1024, d_model 512) only"
+    src = os.path.join(ROOT, "video2music_amd", "csrc", src_name)
+    if not (os.path.exists(PMC_PROFILE) and os.path.exists(src)):
         return None, "no committed PMC pass"
-    prof = json.load(open(path))
-    if prof.get("kernel_source_sha256") != _sha256(src):
-        return None, "profiles/r02_pmc_attn_traffic.json was collected on another version of attn_decode.hip"
-    return round(prof[kind]["traffic_over_algorithmic"] * algorithmic_bytes_per_launch), \
-        "profiles/r02_pmc_attn_traffic.json (committed rocprofv3 --pmc pass on this kernel source, scaled to this run's bytes)"
+    prof = json.load(open(PMC_PROFILE))
+    if prof.get("kernel_source_sha256", {}).get(src_name) != _sha256(src):
+        return None, f"profiles/r03_pmc_decode_step.json was collected on another version of {src_name}"
+    rows = [v for k, v in prof["kernels"].items() if match(k)]
+    n = sum(r["dispatches"] for r in rows)
+    if not n:
+        return None, "kernel not in the committed PMC pass"
+    src_note = "profiles/r03_pmc_decode_step.json (rocprofv3 --pmc passes on this kernel source; launch-weighted mean"
+    if algorithmic_bytes is not None:      # attention: the pass covers every 8th position; its traffic / algorithmic ratio scaled to this run's bytes
+        ratio = sum(r["traffic_bytes_per_launch"] * r["dispatches"] for r in rows) / sum(r["algorithmic_bytes_per_launch"] * r["dispatches"] for r in rows)
+        return round(ratio * algorithmic_bytes), src_note + ", traffic / algorithmic ratio scaled to this run's bytes)"
+    return round(sum(r["traffic_bytes_per_launch"] * r["dispatches"] for r in rows) / n), src_note + ")"
 
 
 def prefill_roofline(B, L, S, H, hd, device, reps=20):
@@ -327,8 +344,8 @@ def roofline(model, f, prim, B, T, cfg):
 
     def rate(nbytes, us):
         return (None, None) if not us else (round(nbytes / us / 1e3, 1), round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4))
-    shape_ok = B == 32 and d == 512 and cfg["num_heads"] == 8
-    traffic, traffic_src = pmc_traffic("self_attn", self_bytes, shape_ok)
+    shape_ok = B == 32 and d == 512 and cfg["num_heads"] == 8 and nl == 6
+    traffic, traffic_src = pmc_traffic("self_attn", shape_ok, self_bytes)
     return {
         "bound": "hbm", "kernel": "attn_decode_kernel<64, true, true, {0,2}, 2> (relative-position self-attention, decode step; FOLD 2 in layers 1-5)",
         "achieved": round(self_bytes / self_us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -342,13 +359,14 @@ def roofline(model, f, prim, B, T, cfg):
         "cross_attn": {"kernel": "attn_decode_kernel<64, false, true, 1, 2> (cross-attention over video K/V, decode step)",
                        "algorithmic_bytes_per_launch": round(cross_bytes), "avg_launch_us": round(cross_us, 3),
                        "achieved": round(cross_bytes / cross_us / 1e3, 1), "frac": round(cross_bytes / cross_us / 1e3 / HBM_PEAK_GBS, 4),
-                       "traffic": pmc_traffic("cross_attn", cross_bytes, shape_ok)[0], "event_pair": ev("cross_attn_decode", cross_bytes)},
+                       "traffic": pmc_traffic("cross_attn", shape_ok, cross_bytes)[0], "event_pair": ev("cross_attn_decode", cross_bytes)},
         "decode_gemm": {"kernel": "decode_gemm_kernel<4,true,0> (G1, G2) and <6,true,2> (G3): weight-streaming skinny GEMMs, 18 launches per step",
                         "packed_weight_bytes_per_launch": round(gemm_bytes),
                         "avg_launch_us": None if gemm_in_chain_us is None else round(gemm_in_chain_us, 3),
                         "achieved": rate(gemm_bytes, gemm_in_chain_us)[0], "frac": rate(gemm_bytes, gemm_in_chain_us)[1],
+                        "traffic": pmc_traffic("decode_gemm", shape_ok)[0], "traffic_source": pmc_traffic("decode_gemm", shape_ok)[1],
                         "measured": "in the chain: (step us - attention launches - sampling head) / GEMM launches; latency-bound "
-                                    "(profiles/r02_skinny_gemm_timeline_before.txt, r02_pmc_decode_step_SQ.json: 86 % of wave cycles waiting)",
+                                    "(profiles/r02_skinny_gemm_timeline_before.txt; wave-cycle split in profiles/r03_pmc_decode_step.json)",
                         "event_pair": ev("decode_gemm", gemm_bytes)},
         "sample_event_pair": ev("sample"),
         "whole_step": whole_step(cfg, B, T, st, full),
