@@ -112,13 +112,13 @@ def free_port():
     return p
 
 
-def run_two(tmp_path, script_text, shared):
+def run_two(tmp_path, script_text, shared, world=2):
     script = tmp_path / "worker.py"
     script.write_text(script_text)
     port = free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), AMT_ROOT=ROOT, SHARED=str(int(shared)), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
@@ -126,9 +126,11 @@ def run_two(tmp_path, script_text, shared):
         assert p.returncode == 0, o
 
 
-@pytest.mark.parametrize("shared", [False, True])
-def test_expert_parallel_orchestration_gloo_cpu(tmp_path, shared):
-    run_two(tmp_path, CPU_WORKER, shared)
+@pytest.mark.parametrize("shared,world", [(False, 2), (True, 2), (False, 4), (True, 8)])
+def test_expert_parallel_orchestration_gloo_cpu(tmp_path, shared, world):
+    """2, 4 and 8 ranks (8 = one expert per rank, BASELINE.json config 5's placement): every rank routes its own, differently sized
+    token set; the orchestration (count exchange, one host sync, dispatch, local experts, return, combine) against the oracle."""
+    run_two(tmp_path, CPU_WORKER, shared, world)
 
 
 @pytest.mark.gpu
