@@ -120,6 +120,8 @@ int32_t amt_generate_run(amt_handle* h, int32_t n_steps, float* logits_out, void
  *   forward(mask=False), :978-982); 1 restores the default.
  *   "decode_chain_plain" = 1 (before the first amt_finalize): the decode step without folded LayerNorms (49 launches instead of
  *   31: model/rpr.py:59-69 operator by operator) -- the chain that shapes outside the fold's range take anyway.
+ *   "fuse_sampling_head" = 0 (any time): every step of a captured decode graph ends with its own sampling-head launch (31 launches
+ *   per step); 1, the default: inside a graph the head rides in the prologue of the next step's first self-attention (30).
  *   "profile_skip" = 1 | 2 | 3 (any time; results become meaningless): measurement hook of bench.py, leaves the self-attention
  *   (bit 0) and / or cross-attention (bit 1) launches out of the captured decode step, so that what a kernel costs the step is
  *   the difference between two timed generates.  0 restores the real step. */

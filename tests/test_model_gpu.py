@@ -132,6 +132,39 @@ def test_folded_and_plain_decode_chains_agree(monkeypatch):
     assert 0 < err < 1e-4, err        # > 0: the two chains really are different arithmetic
 
 
+@pytest.mark.parametrize("mode", ["argmax", "categorical", "top1", "suppress"])
+def test_sampling_head_in_the_next_steps_attention_equals_the_separate_launch(mode):
+    """Inside a captured graph the sampling head of a step rides in the prologue of the NEXT step's first self-attention
+    (attn_decode_sample_kernel: 30 launches per step; `fuse_sampling_head` = 0 keeps the 31-launch chain).  Same decision code, same
+    table sums; the new position's own key is added after the cached ones instead of among them (fp32 summation order), so ids must be
+    equal on a well-conditioned model and logits equal up to rounding.  Primers of three chords (decided positions start at 3),
+    arg-max, the inverse-CDF draw at fixed uniforms, the top-1 branch, and N allowed / three equal chords suppressed."""
+    cfg = dict(CFG1, n_layers=3)
+    m = VideoMusicTransformer(**cfg).eval()
+    m.load_state_dict(synthetic_sd(cfg, 11, recipe="feedback"), strict=False)
+    m = m.cuda()
+    B, T = 5, 70
+    f = cu(feats_t(synthetic.synthetic_features(B, seed=77)))
+    prim = torch.tensor([[1, 1, 0], [66, 6, 0], [122, 10, 5]]).t()
+    kw = dict(target_seq_length=T, beam=0, sampler="argmax", return_logits=True)
+    if mode == "categorical":
+        kw.update(sampler="categorical", uniforms=torch.from_numpy(np.random.RandomState(5).rand(T, B).astype(np.float32)))
+    elif mode == "top1":
+        kw.update(beam=1, one_pass_top1=False)
+    elif mode == "suppress":
+        kw.update(max_conseq_N=1, max_conseq_chord=3)
+    out = {}
+    with torch.no_grad():
+        for fuse in (1, 0):
+            m.set_option("fuse_sampling_head", fuse)
+            out[fuse] = m.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], prim[0], prim[1], prim[2], **kw)
+    assert torch.equal(out[1][0], out[0][0]), (out[1][0], out[0][0])
+    assert torch.equal(out[1][0][:, :3].cpu(), prim[0].view(1, 3).expand(B, 3))
+    err = (out[1][1][:T - 1] - out[0][1][:T - 1]).abs().max().item()
+    assert err < 1e-4, err
+    assert len(set(out[1][0][:, 3:].flatten().tolist())) >= (2 if mode == "top1" else 4)      # (top-1 never feeds its ids back)
+
+
 def test_top1_branch_in_one_pass_equals_the_step_loop(model1):
     """beam=1 (oracle G1) never feeds its ids back, so one teacher-forced forward over (primer, PAD, ...) gives the
     same ids as T-1 decode steps; per-clip primers of length 3."""

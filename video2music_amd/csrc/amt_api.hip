@@ -108,6 +108,7 @@ struct amt_handle {
     bool causal_mask = true;             // amt_set_option("causal_mask"): 0 = the forward without the subsequent mask (mask=False)
     const float* vis_resid = nullptr;    // amt_encode_resid: rows added to Linear_vis's output (scene_embed)
     int skip_mask = 0;                   // amt_set_option("profile_skip"): measurement ablation, 1 = no self-attention launches, 2 = no cross-attention launches
+    bool fuse_head = true;               // amt_set_option("fuse_sampling_head"): inside a captured graph the head rides in the next step's first attention
     bool plain_chain = false;            // amt_set_option("decode_chain_plain"), before the first amt_finalize: the 49-launch chain without folded LayerNorms
     bool gen_active = false;
     // graphs keyed by the parameters baked into the captured kernel arguments
@@ -255,7 +256,9 @@ struct StepProf {
 //   G3  [u3 | qkv_raw] = [relu(norm2-fix(h_raw)) | x2] . [W2 | Wc_c,W'_c]   FFN-down + residual, next layer's raw QKV
 // 5 dependent kernels per layer instead of 8.  Layer 0's q/k/v are table sums written by the sampling head (its input is
 // a sum of embedding-table rows), the last G3 also emits the raw logits, so a step is 6*5 + 1 = 31 launches.
-int32_t enqueue_decoder_step_folded(amt_handle* h, hipStream_t s, StepProf* prof) {
+// fused_sp (captured graphs, round 3): layer 0's self-attention takes the PREVIOUS step's sampling decision in its prologue
+// (attn_decode_sample_kernel) -- the step then needs no sampling-head launch in front of it: 30 launches.
+int32_t enqueue_decoder_step_folded(amt_handle* h, hipStream_t s, StepProf* prof, const SampleParams* fused_sp = nullptr) {
     const int B = h->genB, d = h->d, dff = h->dff, H = h->H, hd = h->hd;
     const float qscale = 1.0f / sqrtf((float)hd);
     int32_t rc;
@@ -268,7 +271,9 @@ int32_t enqueue_decoder_step_folded(amt_handle* h, hipStream_t s, StepProf* prof
         AttnDecodeParams a{};
         a.k = Kc; a.v = Vc; a.o = h->ob; a.B = B; a.H = H; a.hd = hd; a.cap = h->kv_rows;
         a.pos = h->pos; a.Er = L.Er; a.er_len = h->Tcap;
-        if (l == 0) {
+        if (l == 0 && fused_sp) {
+            a.k_new = Kc; a.v_new = Vc; a.new_kv = 1;      // q / k / v of the new position are summed from the projected tables in the kernel
+        } else if (l == 0) {
             a.q = h->qb;          // written, with this position's K/V rows, by the previous sampling head / embed_step (table sums)
         } else {
             const DecLayer& P = h->dec[l - 1];
@@ -276,7 +281,9 @@ int32_t enqueue_decoder_step_folded(amt_handle* h, hipStream_t s, StepProf* prof
             a.fold_lnw = P.n3w; a.fold_lnb = P.n3b; a.xn = h->xa; a.new_kv = 1; a.k_new = Kc; a.v_new = Vc;
             a.eps = LN_EPS; a.q_scale = qscale;
         }
-        if (!(h->skip_mask & 1)) {
+        if (l == 0 && fused_sp) {
+            if ((rc = amt_launch_attn_decode_sample(a, *fused_sp, s))) return rc;
+        } else if (!(h->skip_mask & 1)) {
             PROF_BEGIN();
             if ((rc = amt_launch_attn_decode(a, s))) return rc;
             PROF_END(0);
@@ -398,7 +405,7 @@ int32_t enqueue_decoder_step(amt_handle* h, hipStream_t s, StepProf* prof = null
 }
 
 int32_t get_graph(amt_handle* h, int nsteps, float* logits_out, hipGraphExec_t* out) {
-    amt_handle::GraphKey key{h->genB, h->genT, h->genP, h->beam, h->mcN, h->mcC, h->encS, nsteps, h->skip_mask, h->use_unif, logits_out};
+    amt_handle::GraphKey key{h->genB, h->genT, h->genP, h->beam, h->mcN, h->mcC, h->encS, nsteps, h->skip_mask | (h->fuse_head ? 4 : 0), h->use_unif, logits_out};
     for (auto& g : h->graphs)
         if (memcmp(&g.key, &key, sizeof(key)) == 0) { *out = g.exec; return 0; }
     hipGraph_t graph;
@@ -408,9 +415,15 @@ int32_t get_graph(amt_handle* h, int nsteps, float* logits_out, hipGraphExec_t* 
     hipStream_t cs = h->cap_stream;
     AMT_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
     int32_t rc = 0;
+    // Inside a graph the sampling head between two steps rides in the prologue of the following step's first self-attention
+    // (folded chain, decision on the device): [step, head] x n becomes step, (head+step) x (n-1), head.  The measurement hook that
+    // leaves the self-attention launches out keeps the separate head (the decision must still happen).
+    const SampleParams sp = sample_params(h, logits_out, nullptr, 0);
+    const bool fuse = h->fold && h->fuse_head && !(h->skip_mask & 1);
     for (int i = 0; i < nsteps && !rc; ++i) {
-        rc = enqueue_decoder_step(h, cs);
-        if (!rc) rc = amt_launch_sample(sample_params(h, logits_out, nullptr, 0), cs);
+        if (fuse && i > 0) rc = enqueue_decoder_step_folded(h, cs, nullptr, &sp);
+        else rc = enqueue_decoder_step(h, cs);
+        if (!rc && !(fuse && i + 1 < nsteps)) rc = amt_launch_sample(sp, cs);
     }
     hipError_t e = hipStreamEndCapture(cs, &graph);
     if (rc) { if (e == hipSuccess) (void)hipGraphDestroy(graph); return rc; }
@@ -685,6 +698,10 @@ extern "C" int32_t amt_set_option(amt_handle* h, const char* name, int32_t value
         h->plain_chain = value != 0;
         return 0;
     }
+    if (strcmp(name, "fuse_sampling_head") == 0) {           // 0: every step of a captured graph ends with its own sampling-head launch (31 per step)
+        h->fuse_head = value != 0;
+        return 0;
+    }
     if (strcmp(name, "profile_skip") == 0) {                 // measurement hook of bench.py: leave a kernel class out of the captured step
         AMT_CHECK_ARG(value >= 0 && value < 4, "amt_set_option: profile_skip takes 0 (none), 1 (self-attention), 2 (cross-attention) or 3");
         h->skip_mask = value;
@@ -863,7 +880,9 @@ extern "C" int32_t amt_generate_run(amt_handle* h, int32_t n_steps, float* logit
     int left = n_steps;
     const int spg = amt_tuning().steps_per_graph;
     while (left > 0) {
-        const int ns = left >= spg ? spg : 1;
+        int ns = spg;                               // whole graphs, then the remainder in halves (each size is captured once)
+        while (ns > left) ns >>= 1;
+        if (ns < 1) ns = 1;
         hipGraphExec_t exec;
         if ((rc = get_graph(h, ns, logits_out, &exec))) return rc;
         AMT_HIP(hipGraphLaunch(exec, s));

@@ -89,7 +89,8 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // environment variable and keeps no other mutable global besides the per-device attribute flags guarded by mutexes.
 struct AmtTuning {
     int kv_pad = -1;              // AMT_KV_PAD: padding rows per (clip, head) slice of the self-attention cache; -1 = make Tcap odd
-    int steps_per_graph = 8;      // AMT_STEPS_PER_GRAPH: decode steps per captured hipGraph
+    int steps_per_graph = 16;     // AMT_STEPS_PER_GRAPH: decode steps per captured hipGraph (a power of two; the first step of a graph keeps its
+                                  // separate sampling head, the others take the decision in their first attention)
     int nt_mask = 3;              // AMT_NT: non-temporal K/V loads, bit 0 self-attention, bit 1 cross-attention
     int wide_grouped = 1;         // AMT_WIDE_GROUPED: grouped down-projections on the wide skinny GEMM
     int wide_ntw = 4;             // AMT_WIDE_NTW: column tiles per workgroup of the wide skinny GEMM

@@ -15,6 +15,7 @@
 
 #include "amt_common.h"
 #include "kernels.h"
+#include "sample_device.h"
 
 namespace {
 
@@ -108,7 +109,11 @@ constexpr int UCH_MAX = 4;       // folded prologue: the pre-LN row has at most 
 
 // FOLD: 0 plain query, 1 folded-LayerNorm prologue, 2 the same plus the new key/value of this position, 3 = 1 plus the rotary
 // embedding of the query (the lockstep V1/V2 step: q = rope(LayerNorm(u) . Wq^T + b) * scale), 4 = 2 plus the rotary embedding of
-// the query and of the new key (the V1/V2 self-attention behind a folded norm3; no relative-position table)
+// the query and of the new key (the V1/V2 self-attention behind a folded norm3; no relative-position table), 5 = the base model's
+// layer-0 self-attention with the PREVIOUS step's sampling decision in its prologue (attn_decode_sample_kernel): wave 0 takes the
+// decision of the folded output head for its clip (sample_device.h), every wave then sums its head's q / k / v of the new position
+// from the projected input tables, head 0 stores the token and the next input row, the launch's last workgroup advances the
+// position -- the sampling head's launch between two steps of a captured graph disappears
 #ifdef AMT_STAMPS
 #define ASTAMP(i) do { __builtin_amdgcn_sched_barrier(0); st_[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -116,11 +121,7 @@ constexpr int UCH_MAX = 4;       // folded prologue: the pre-LN row has at most 
 #endif
 
 template <int HD, bool RPR, bool NT, int FOLD, int UCH>
-// hd = 64 at d_model <= 512 (the benchmark's shape) is held at 128 VGPRs = two workgroups per CU: it fits without spilling and a
-// launch of more than 256 workgroups (more than 32 clips per chain) then runs in one round (+6-7 % tokens/s at 64-256 clips); the
-// other shapes keep the compiler's own choice (the same bound makes the hd = 16 / 32 relative-position variants spill)
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((HD == 64 && UCH == 2) ? 4 : 1, (HD == 64 && UCH == 2) ? 4 : 8)))
-void attn_decode_kernel(AttnDecodeParams p) {
+__device__ __forceinline__ void attn_decode_body(const AttnDecodeParams& p, const SampleParams* sp) {
 #ifdef AMT_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -143,18 +144,81 @@ void attn_decode_kernel(AttnDecodeParams p) {
     // read (rows past the current length are fetched but never used; they lie inside the cache).
     Batch<HD> b0, b1;
     int j0 = wave * KPW;
-    const int t = p.pos ? *p.pos : (p.n_keys - 1);   // issued here: the prologue's stores would pin it behind them
+    // issued here: the prologue's stores would pin it behind them.  FOLD 5: *pos is the position the PREVIOUS step processed
+    const int t = FOLD == 5 ? *p.pos + 1 : (p.pos ? *p.pos : (p.n_keys - 1));
     float4 q4, kn4 = make_float4(0.f, 0.f, 0.f, 0.f), vn4 = kn4;
-    constexpr bool fresh = FOLD == 2 || FOLD == 4;   // key/value of position t live in registers, not in the cache
+    constexpr bool fresh = FOLD == 2 || FOLD == 4 || FOLD == 5;   // key/value of position t live in registers, not in the cache
     const int n_keys = fresh ? t : t + 1;
     const float* eb = RPR ? p.Er + (size_t)(p.er_len - 1 - t) * HD : nullptr;   // Er row of key 0 (wave-uniform)
     // Vector loads return in issue order.  The long prologue of FOLD 2 (11 loads and their address math) goes
     // behind the first K/V batch so that the stream starts at once; the short one of FOLD 1 goes in front of it
     // so that the statistics are computed while the batch is in flight (measured both ways).
     constexpr bool F1 = FOLD == 1 || FOLD == 3;
+    __shared__ int s_ra[2];
+    if constexpr (FOLD == 5) {
+        // ---- the sampling head of the previous step (sample_fold_kernel's work, model/video_music_transformer.py:1070-1123), wave 0,
+        // IN FRONT of its share of the key stream: vector loads return in issue order, behind two K/V batches the decision's rows
+        // would land microseconds later; the other seven waves start streaming at once ----
+        if (wave == 0) {
+            const SampleParams& q = *sp;
+            int root, attr;
+            if (t >= q.n_primer) {
+                const int tok = decide_fold_wave<UCH>(q, b, t - 1, lane, h == 0);
+                feedback_of(q, tok, root, attr);
+                if (h == 0 && lane == 0) {
+                    q.tokens[(size_t)b * q.T + t] = tok;
+                    q.roots[(size_t)b * q.T + t] = root;
+                    q.attrs[(size_t)b * q.T + t] = attr;
+                }
+            } else {
+                // inside the primer the token is given; the logits of the previous position are still owed to a caller who asked for them
+                if (q.logits_out && h == 0) (void)decide_fold_wave<UCH>(q, b, t - 1, lane, true);
+                root = (int)q.roots[(size_t)b * q.T + t];
+                attr = (int)q.attrs[(size_t)b * q.T + t];
+            }
+            if (lane == 0) { s_ra[0] = root; s_ra[1] = attr; }
+        }
+    }
     if (!F1) load_kv<HD, NT>(b0, kb, vb, j0, sub, c4, p.cap);
     if (!FOLD) {
         q4 = ld4(p.q + ((size_t)b * p.H + h) * HD + c * 4);
+    } else if constexpr (FOLD == 5) {
+        // The decision (above) and the table rows behind it are two serial L2 round trips before the query exists: the key stream
+        // runs meanwhile -- the Er rows of the first batch and the whole SECOND batch are requested here (rows past the end clamp to
+        // row 0), so the HBM stream does not idle behind the prologue
+        if (RPR) load_er<HD>(b0, eb, j0, sub, c4, n_keys);
+        load_batch<HD, RPR, NT>(b1, kb, vb, eb, j0 + STRIDE, sub, c4, n_keys);
+        const SampleParams& q = *sp;
+        __syncthreads();
+        const int root = s_ra[0], attr = s_ra[1];
+        // this head's q / k / v of position t: the decoder input is a sum of table rows, so its projection is one too (the
+        // summation order of write_next_input in sample.hip: ((TR[root] + TA[attr]) + key * tk) + TP[t])
+        const int d = q.d, d3 = 3 * d, col = h * HD + c * 4;
+        const float kv = q.key[b];
+        const float* tr = q.tab_r + (size_t)root * d3 + col;
+        const float* ta = q.tab_a + (size_t)attr * d3 + col;
+        const float* tk = q.tab_k + col;
+        const float* tp = q.tab_p + (size_t)t * d3 + col;
+        const float4 r0 = ld4(tr), a0 = ld4(ta), k0 = ld4(tk), p0 = ld4(tp);
+        const float4 r1 = ld4(tr + d), a1 = ld4(ta + d), k1 = ld4(tk + d), p1 = ld4(tp + d);
+        const float4 r2 = ld4(tr + 2 * d), a2 = ld4(ta + 2 * d), k2 = ld4(tk + 2 * d), p2 = ld4(tp + 2 * d);
+        __builtin_amdgcn_sched_barrier(0);
+        q4.x = (((r0.x + a0.x) + kv * k0.x) + p0.x) * q.q_scale; q4.y = (((r0.y + a0.y) + kv * k0.y) + p0.y) * q.q_scale;
+        q4.z = (((r0.z + a0.z) + kv * k0.z) + p0.z) * q.q_scale; q4.w = (((r0.w + a0.w) + kv * k0.w) + p0.w) * q.q_scale;
+        kn4.x = ((r1.x + a1.x) + kv * k1.x) + p1.x; kn4.y = ((r1.y + a1.y) + kv * k1.y) + p1.y;
+        kn4.z = ((r1.z + a1.z) + kv * k1.z) + p1.z; kn4.w = ((r1.w + a1.w) + kv * k1.w) + p1.w;
+        vn4.x = ((r2.x + a2.x) + kv * k2.x) + p2.x; vn4.y = ((r2.y + a2.y) + kv * k2.y) + p2.y;
+        vn4.z = ((r2.z + a2.z) + kv * k2.z) + p2.z; vn4.w = ((r2.w + a2.w) + kv * k2.w) + p2.w;
+        if (h == 0) {                                 // the next input row x[t] (the residual stream layer 0 starts from)
+            for (int cc = threadIdx.x * 4; cc < d; cc += NW * 64 * 4) {
+                const float4 pr = ld4(q.PR + (size_t)root * d + cc), pa = ld4(q.PA + (size_t)attr * d + cc);
+                const float4 wk = ld4(q.wkey + cc), bb = ld4(q.cbias + cc), pp = ld4(q.pe + (size_t)t * d + cc);
+                float4 o4;
+                o4.x = ((pr.x + pa.x) + kv * wk.x + bb.x) + pp.x; o4.y = ((pr.y + pa.y) + kv * wk.y + bb.y) + pp.y;
+                o4.z = ((pr.z + pa.z) + kv * wk.z + bb.z) + pp.z; o4.w = ((pr.w + pa.w) + kv * wk.w + bb.w) + pp.w;
+                st4(q.x_next + (size_t)b * d + cc, o4);
+            }
+        }
     } else {
         // LayerNorm folded through the projection: q = ((raw - mu*g) * rstd + c) * q_scale with the row
         // statistics of the pre-LN sum u[b] (every wave recomputes them: d floats from L2, two DPP reductions).
@@ -251,9 +315,15 @@ void attn_decode_kernel(AttnDecodeParams p) {
         st4(p.v_new + (((size_t)b * p.H + h) * p.cap + t) * HD + c * 4, vn4);
     }
     if (RPR && !fresh) load_er<HD>(b0, eb, j0, sub, c4, n_keys);
+    // (fresh variants requested the first batch's Er rows inside their prologue)
     float m = -INFINITY, l = 0.f;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!RPR) {
+    if constexpr (FOLD == 5) {
+        // both batches are in flight since the prologue
+        consume_batch<HD, RPR>(b0, q4, j0, sub, n_keys, m, l, o);
+        j0 += STRIDE;
+        stream_keys<HD, RPR, NT>(b1, b0, kb, vb, eb, q4, j0, sub, c4, n_keys, m, l, o);
+    } else if (!RPR) {
         // cross-attention (fixed key count, always several batches): the first half-iteration is peeled, which keeps the
         // wait counts of the loop exact on both halves (measured 7.0 -> 6.8 us); for the self-attention the extra
         // unconditional batch at short lengths costs more than it gains (12.7 -> 13.1 us), so it enters the loop directly
@@ -333,6 +403,33 @@ void attn_decode_kernel(AttnDecodeParams p) {
         for (int i = 0; i < 8; ++i) o[i] = st_[i];
     }
 #endif
+    if constexpr (FOLD == 5) {
+        // every workgroup read *pos at its start; the last one to arrive publishes the position this step processes
+        if (threadIdx.x == 0) {
+            const unsigned n = __hip_atomic_fetch_add(sp->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (n == gridDim.x * gridDim.y - 1) {
+                *sp->pos = t;
+                __hip_atomic_store(sp->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+template <int HD, bool RPR, bool NT, int FOLD, int UCH>
+// hd = 64 at d_model <= 512 (the benchmark's shape) is held at 128 VGPRs = two workgroups per CU: it fits without spilling and a
+// launch of more than 256 workgroups (more than 32 clips per chain) then runs in one round (+6-7 % tokens/s at 64-256 clips); the
+// other shapes keep the compiler's own choice (the same bound makes the hd = 16 / 32 relative-position variants spill)
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((HD == 64 && UCH == 2) ? 4 : 1, (HD == 64 && UCH == 2) ? 4 : 8)))
+void attn_decode_kernel(AttnDecodeParams p) {
+    attn_decode_body<HD, RPR, NT, FOLD, UCH>(p, nullptr);
+}
+
+// layer 0 of the base model's folded chain with the previous step's decision in front (FOLD 5).  No 128-VGPR bound here: with the
+// first K/V batch in flight the decision and the twelve table rows need more (the bound spilled 36 registers); at 32 clips the launch is
+// one workgroup per CU either way, above that this ONE launch of the step's six self-attentions takes two rounds
+template <int HD, bool RPR, bool NT, int UCH>
+__global__ __launch_bounds__(NW * 64) void attn_decode_sample_kernel(AttnDecodeParams p, SampleParams sp) {
+    attn_decode_body<HD, RPR, NT, 5, UCH>(p, &sp);
 }
 
 template <int HD, int FOLD, int UCH>
@@ -360,7 +457,43 @@ void launch_decode(const AttnDecodeParams& p, hipStream_t stream) {
     else launch_decode_u<HD, FOLD, 4>(p, stream);
 }
 
+template <int HD>
+void launch_decode_sample(const AttnDecodeParams& p, const SampleParams& sp, hipStream_t stream) {
+    dim3 grid(p.H, p.B);
+    const bool nt = (amt_tuning().nt_mask & 1) != 0;
+#define AMT_LAUNCH_DS(RPR, NTV, UCHV) hipLaunchKernelGGL((attn_decode_sample_kernel<HD, RPR, NTV, UCHV>), grid, dim3(NW * 64), 0, stream, p, sp)
+    if (sp.d <= 512) {
+        if (p.Er) { if (nt) AMT_LAUNCH_DS(true, true, 2); else AMT_LAUNCH_DS(true, false, 2); }
+        else { if (nt) AMT_LAUNCH_DS(false, true, 2); else AMT_LAUNCH_DS(false, false, 2); }
+    } else {
+        if (p.Er) { if (nt) AMT_LAUNCH_DS(true, true, 4); else AMT_LAUNCH_DS(true, false, 4); }
+        else { if (nt) AMT_LAUNCH_DS(false, true, 4); else AMT_LAUNCH_DS(false, false, 4); }
+    }
+#undef AMT_LAUNCH_DS
+}
+
 }  // namespace
+
+// The base model's layer-0 self-attention of a decode step with the previous step's sampling decision in its prologue (FOLD 5):
+// p as for the plain layer-0 launch (k / v the cache, pos the device position) plus k_new / v_new; sp as amt_launch_sample takes it
+// (folded head: lraw, h1..h4, projected tables).  *pos must hold the position the previous step processed.
+int32_t amt_launch_attn_decode_sample(const AttnDecodeParams& p, const SampleParams& sp, hipStream_t stream) {
+    AMT_CHECK_ARG(p.B > 0 && p.H > 0 && p.cap > 0 && p.pos && p.pos == sp.pos && p.k_new && p.v_new, "attn_decode_sample: bad attention arguments");
+    AMT_CHECK_ARG(sp.lraw && sp.h1 && sp.h2 && sp.h3 && sp.h4 && sp.ln_w && sp.ln_b && sp.tab_r && sp.tab_a && sp.tab_k && sp.tab_p && sp.ticket &&
+                  sp.tokens && sp.roots && sp.attrs && sp.x_next && !sp.sample_external && !sp.probs_out,
+                  "attn_decode_sample: needs the folded head, the projected input tables and a device-side decision");
+    AMT_CHECK_ARG(sp.B == p.B && sp.d == p.H * p.hd && sp.d % 4 == 0 && sp.d <= UCH_MAX * 256, "attn_decode_sample: shapes of the two halves differ");
+    AMT_CHECK_ARG(p.Er == nullptr || p.er_len + 1 >= p.cap, "attn_decode_sample: er_len=%d smaller than the key capacity %d", p.er_len, p.cap);
+    switch (p.hd) {
+        case 16: launch_decode_sample<16>(p, sp, stream); break;
+        case 32: launch_decode_sample<32>(p, sp, stream); break;
+        case 64: launch_decode_sample<64>(p, sp, stream); break;
+        case 128: launch_decode_sample<128>(p, sp, stream); break;
+        default: AMT_CHECK_ARG(false, "attn_decode_sample: head_dim %d not in {16,32,64,128}", p.hd);
+    }
+    AMT_LAUNCH_CHECK();
+    return 0;
+}
 
 int32_t amt_launch_attn_decode(const AttnDecodeParams& p, hipStream_t stream) {
     AMT_CHECK_ARG(p.B > 0 && p.H > 0 && p.cap > 0, "attn_decode: bad shape B=%d H=%d cap=%d", p.B, p.H, p.cap);

@@ -11,7 +11,9 @@ pids=()
 for src in "$HERE"/*.hip; do
   obj="$HERE/obj/$(basename "${src%.hip}").o"
   objs+=("$obj")
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/kernels.h" -nt "$obj" ] || [ "$HERE/amt_common.h" -nt "$obj" ] || [ "$HERE/../../include/amt_hip.h" -nt "$obj" ]; then
+  stale=0
+  for hdr in "$HERE"/*.h "$HERE/../../include/amt_hip.h"; do [ "$hdr" -nt "$obj" ] && stale=1; done
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ $stale = 1 ]; then
     $HIPCC $FLAGS -c "$src" -o "$obj" &
     pids+=($!)
   fi

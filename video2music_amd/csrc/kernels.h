@@ -231,5 +231,7 @@ struct SampleParams {
     int chord_embed;                 // 1: the chosen chord id feeds back as the "root" index (table = chord embedding), attr = 0
 };
 int32_t amt_launch_sample(const SampleParams& p, hipStream_t stream);
+// the base model's layer-0 self-attention with the previous step's sampling decision in its prologue (attn_decode.hip, FOLD 5)
+int32_t amt_launch_attn_decode_sample(const AttnDecodeParams& p, const SampleParams& sp, hipStream_t stream);
 // writes x_next for position *pos from the token sequences (start of generate / external sampling)
 int32_t amt_launch_embed_step(const SampleParams& p, int advance, hipStream_t stream);

@@ -24,7 +24,7 @@ const AmtTuning& amt_tuning() {
         getl("AMT_GEMM_SMALL_M", t.gemm_small_m); getl("AMT_GEMM_SMALL_MN", t.gemm_small_mn);
         geti("AMT_GEMM_T64_BELOW", t.gemm_t64_below); geti("AMT_GEMM_PF", t.gemm_pf);
         int dbg = 0; geti("AMT_DBG", dbg); t.prepacked = (dbg & 16) ? 1 : 0;
-        if (t.steps_per_graph <= 0) t.steps_per_graph = 8;
+        if (t.steps_per_graph <= 0) t.steps_per_graph = 16;
     });
 #endif
     return t;

@@ -408,6 +408,10 @@ class VideoMusicTransformer(nn.Module):
         """bench.py only: leave the self- (1) / cross- (2) attention launches out of the decode step."""
         _lib.call("amt_set_option", self._ensure_handle(), b"profile_skip", int(mask))
 
+    def set_option(self, name, value):
+        """A handle option of the library (include/amt_hip.h: amt_set_option), e.g. ("fuse_sampling_head", 0)."""
+        _lib.call("amt_set_option", self._ensure_handle(), name.encode(), int(value))
+
     def generate_profile(self, feature_semantic_list, feature_key, feature_scene_offset, feature_motion, feature_emotion,
                          primer, primer_root, primer_attr, target_seq_length=300, max_conseq_N=0, max_conseq_chord=2):
         """One feedback-greedy generate (<= 32 clips) issued eagerly with HIP events around every
