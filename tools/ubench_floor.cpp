@@ -42,7 +42,7 @@ int main() {
     CK(hipMalloc(&p, 1 << 20)); CK(hipMalloc(&q, big)); CK(hipMalloc(&idx, 64));
     CK(hipMemset(idx, 0, 64)); CK(hipMemset(q, 0, big));
     CK(hipFuncSetAttribute((const void*)k_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    for (int wg : {32, 96, 256}) for (int th : {256, 512}) {
+    for (int wg : {32, 96, 128, 192, 256}) for (int th : {256, 512, 1024}) {
         char n[128];
         snprintf(n, 128, "empty <<<%d,%d>>>", wg, th); bench(n, [&](hipStream_t s) { hipLaunchKernelGGL(k_empty, dim3(wg), dim3(th), 0, s, p); });
         snprintf(n, 128, "store <<<%d,%d>>>", wg, th); bench(n, [&](hipStream_t s) { hipLaunchKernelGGL(k_store, dim3(wg), dim3(th), 0, s, p); });

@@ -27,7 +27,11 @@ constexpr int KT = 32;       // keys per tile
 // NOMASK: relative positions WITHOUT the causal mask (forward(mask=False)); a separate instantiation so that the causal kernel
 // of the hot path keeps its exact instruction stream
 template <int HD, bool RPR, bool NOMASK = false>
-__global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
+// without the relative-position term (cross-attention, the encoder, GQA) and head_dim <= 64 the kernel is held at 168 registers = THREE
+// waves per SIMD (three 51 KB workgroups per CU): two resident workgroups drift into lockstep -- both in their MFMA phases, then both in
+// their softmax -- and the matrix pipe idles meanwhile; a third one fills the gaps
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!RPR && HD <= 64) ? 3 : 1, (!RPR && HD <= 64) ? 3 : 8)))
+void attn_prefill_kernel(AttnParams p) {
     constexpr int HDP = HD < 32 ? 32 : HD;   // head_dim 16: the O^T tile is still 32 rows of d; V columns 16..31 are zeros in LDS
     constexpr int LD = HDP + 4;
     constexpr int NS = HD / 8;           // ds_read_b128 k-groups per operand row
