@@ -62,7 +62,8 @@ int32_t amt_abi_version(void);
 
 /* ---- model lifetime -------------------------------------------------------------------- */
 /* Shapes the handle takes (anything else is refused with a message, never computed wrongly): d_model a multiple of 32 with
- * 64 <= d_model <= 1024; head_dim = d_model / num_heads in {16, 32, 64, 128}; dim_feedforward a multiple of 32, <= 1536;
+ * 64 <= d_model <= 1024; head_dim = d_model / num_heads in {16, 32, 64, 128}; dim_feedforward a multiple of 32, <= 8192 (beyond d_model + dim_feedforward = 1536 the decode step runs without folded LayerNorms, beyond
+ * dim_feedforward = 1536 its linear2 product runs in column ranges of 1024);
  * max_batch 1..256 clips per decode chain (larger batches are sliced by the caller, video2music_amd/model). */
 int32_t amt_create(const amt_config* cfg, amt_handle** out);
 int32_t amt_destroy(amt_handle* h);

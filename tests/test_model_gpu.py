@@ -196,6 +196,34 @@ def test_shapes_outside_the_fold_fall_back_to_the_plain_chain(over):
     assert torch.equal(out.cpu(), ref)
 
 
+@pytest.mark.parametrize("ff", [2048, 2560])
+def test_feed_forward_wider_than_the_skinny_gemm_stages(ff):
+    """dim_feedforward beyond 1536 (round 3: the cap was 1536): the decode step takes the plain chain and runs linear2 in column ranges
+    of 1024 (2560 = 1024 + 1024 + 512), each range adding onto the ones before; forward logits and greedy ids against the oracle."""
+    cfg = dict(CFG1, dim_feedforward=ff, n_layers=2)
+    m, sd = build(cfg, seed=ff)
+    fc = feats_t(synthetic.synthetic_features(2, seed=ff + 1))
+    f = cu(fc)
+    pr, prr, pra = (torch.tensor([v]) for v in C.primer_from_name("C"))
+    T = 24
+    with torch.no_grad():
+        out = m.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], pr, prr, pra, target_seq_length=T,
+                               beam=0, sampler="argmax").cpu()
+        rs = np.random.RandomState(ff)
+        root = torch.from_numpy(rs.randint(1, 13, size=(2, 12)))
+        attr = torch.from_numpy(rs.randint(1, 14, size=(2, 12)))
+        y = m(root.cuda(), root.cuda(), attr.cuda(), f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"]).cpu()
+    ref_y = O.forward(sd, cfg["num_heads"], root, attr, fc["semantic"], fc["key"], fc["scene_offset"], fc["motion"], fc["emotion"])
+    assert (y - ref_y).abs().max().item() < LOGIT_TOL
+    for b in range(2):
+        one = {k: v[b:b + 1] for k, v in fc.items()}
+        margins = []
+        ref = O.generate(sd, cfg["num_heads"], one["semantic"], one["key"], one["scene_offset"], one["motion"], one["emotion"], pr, prr, pra,
+                         target_seq_length=T, beam=0, margins=margins)
+        assert min(margins) > 1e-4, margins
+        assert torch.equal(out[b:b + 1], ref), (b, out[b], ref)
+
+
 @pytest.mark.parametrize("d,H,ff", [(256, 4, 64), (128, 8, 64)])
 def test_plain_chain_with_a_feed_forward_narrower_than_the_model(monkeypatch, d, H, ff):
     """The 49-launch chain (AMT_DECODE_CHAIN=plain) publishes LayerNorm(u2) from the prologue of the FFN-up product: with

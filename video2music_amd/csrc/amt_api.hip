@@ -38,6 +38,7 @@ namespace {
 constexpr int V = 159;
 constexpr float LN_EPS = 1e-5f;
 constexpr int VS = 160;                  // V rounded up to the skinny GEMM's 16-column tiles
+constexpr int FFN_CHUNK = 1024;          // column range of linear2 per skinny-GEMM launch when dim_feedforward > 1536
 
 struct Tensor {
     float* p = nullptr;
@@ -397,9 +398,22 @@ int32_t enqueue_decoder_step(amt_handle* h, hipStream_t s, StepProf* prof = null
         DecodeGemmParams f2{};
         f2.B = B; f2.eps = LN_EPS; f2.scale = 1.f; f2.x = h->hb; f2.ldx = dff; f2.Wp = L.p_l2; f2.bias = L.l2b; f2.N = d; f2.K = dff;
         f2.resid = h->xc; f2.ldr = d; f2.y = h->u3; f2.ldy = d;
-        PROF_BEGIN();
-        if ((rc = amt_launch_decode_gemm(f2, s))) return rc;
-        PROF_END(2);
+        if (dff <= 1536) {
+            PROF_BEGIN();
+            if ((rc = amt_launch_decode_gemm(f2, s))) return rc;
+            PROF_END(2);
+        } else {
+            // dim_feedforward beyond the skinny GEMM's 1536 staged columns: column ranges of 1024, every range adding onto the sum of
+            // the ones before it (the first takes the bias and the residual)
+            for (int k0 = 0; k0 < dff; k0 += FFN_CHUNK) {
+                DecodeGemmParams c = f2;
+                c.x = h->hb + k0; c.K = std::min(FFN_CHUNK, dff - k0); c.Wp = L.p_l2 + (size_t)cdiv(d, 16) * 16 * k0;
+                if (k0) { c.bias = nullptr; c.resid = h->u3; }
+                PROF_BEGIN();
+                if ((rc = amt_launch_decode_gemm(c, s))) return rc;
+                PROF_END(2);
+            }
+        }
     }
     return 0;
 }
@@ -452,7 +466,7 @@ extern "C" int32_t amt_create(const amt_config* c, amt_handle** out) {
     const int hd = c->d_model / c->num_heads;
     AMT_CHECK_ARG(hd == 16 || hd == 32 || hd == 64 || hd == 128, "amt_create: head_dim %d not in {16,32,64,128}", hd);
     AMT_CHECK_ARG(c->d_model % 32 == 0 && c->d_model >= 64 && c->d_model <= 1024, "amt_create: d_model must be a multiple of 32, 64 <= d_model <= 1024");
-    AMT_CHECK_ARG(c->dim_feedforward % 32 == 0 && c->dim_feedforward <= 1536, "amt_create: dim_feedforward must be a multiple of 32 and <= 1536");
+    AMT_CHECK_ARG(c->dim_feedforward % 32 == 0 && c->dim_feedforward <= 8192, "amt_create: dim_feedforward must be a multiple of 32 and <= 8192");
     AMT_CHECK_ARG(c->max_batch > 0 && c->max_batch <= 256, "amt_create: max_batch must be in 1..256 (shard larger batches)");
     AMT_CHECK_ARG(c->max_sequence_video > 0 && c->max_sequence_chord > 0 && c->total_vf_dim > 0, "amt_create: bad sequence dims");
     amt_handle* h = new amt_handle();
@@ -637,7 +651,16 @@ extern "C" int32_t amt_finalize(amt_handle* h) {
         if ((rc = pack(h, D.ca_w, (int)d, (int)d, &D.p_caq, s))) return rc;      // q rows 0:d of the packed in-proj
         if ((rc = pack(h, D.ca_ow, (int)d, (int)d, &D.p_cao, s))) return rc;
         if ((rc = pack(h, D.l1w, (int)dff, (int)d, &D.p_l1, s))) return rc;
-        if ((rc = pack(h, D.l2w, (int)d, (int)dff, &D.p_l2, s))) return rc;
+        // linear2 (d x dff): the skinny GEMM stages K <= 1536 input columns; a wider feed-forward is packed -- and multiplied, see
+        // FFN_CHUNK -- in column ranges of 1024, one packed block behind the other
+        if (dff <= 1536) { if ((rc = pack(h, D.l2w, (int)d, (int)dff, &D.p_l2, s))) return rc; }
+        else {
+            if (!D.p_l2 && (rc = dev_alloc(h, &D.p_l2, (size_t)cdiv((int)d, 16) * 16 * dff))) return rc;
+            for (int k0 = 0; k0 < (int)dff; k0 += FFN_CHUNK) {
+                const int kc = std::min(FFN_CHUNK, (int)dff - k0);
+                if ((rc = amt_launch_pack_weight(D.l2w + k0, D.p_l2 + (size_t)cdiv((int)d, 16) * 16 * k0, (int)d, kc, s, (int)dff))) return rc;
+            }
+        }
         if (h->fold) {
             if ((rc = build_fold(h, D.ca_w, (int)d, D.n1w, D.n1b, D.ca_b, D.sa_ow, (int)d, D.sa_ob, &D.pf_a, &D.va, s))) return rc;
             if ((rc = build_fold(h, D.l1w, (int)dff, D.n2w, D.n2b, D.l1b, D.ca_ow, (int)d, D.ca_ob, &D.pf_b, &D.vb, s))) return rc;

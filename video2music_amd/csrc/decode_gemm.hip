@@ -26,14 +26,15 @@ namespace {
 constexpr int MAXB = 4096;       // rows per launch (16 per workgroup, blockIdx.y); the decode step uses 32
 constexpr int XPAD = 8;
 
-__global__ void pack_weight_kernel(const float* __restrict__ W, float* __restrict__ P, int N, int K) {
+// (ldw: row stride of W in floats -- a column range [k0, k0 + K) of a wider matrix is packed as W + k0 with ldw = its full width)
+__global__ void pack_weight_kernel(const float* __restrict__ W, float* __restrict__ P, int N, int K, int ldw) {
     const int kt_n = K / 16;
     const size_t tile = blockIdx.x;                 // nt*kt_n + kt
     const int nt = (int)(tile / kt_n), kt = (int)(tile % kt_n);
     const int lane = threadIdx.x;
     const int n = nt * 16 + (lane & 15), k = kt * 16 + 4 * (lane >> 4);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (n < N) v = ld4(W + (size_t)n * K + k);
+    if (n < N) v = ld4(W + (size_t)n * ldw + k);
     st4(P + (tile * 64 + lane) * 4, v);
 }
 
@@ -706,10 +707,10 @@ int32_t launch_variant(const DecodeGemmParams& p, size_t lds, hipStream_t stream
 
 }  // namespace
 
-int32_t amt_launch_pack_weight(const float* W, float* P, int N, int K, hipStream_t stream) {
-    AMT_CHECK_ARG(K % 16 == 0, "pack_weight: K=%d must be a multiple of 16", K);
+int32_t amt_launch_pack_weight(const float* W, float* P, int N, int K, hipStream_t stream, int ldw) {
+    AMT_CHECK_ARG(K % 16 == 0 && (ldw == 0 || (ldw >= K && ldw % 4 == 0)), "pack_weight: K=%d must be a multiple of 16 (ldw=%d)", K, ldw);
     const int tiles = cdiv(N, 16) * (K / 16);
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(tiles), dim3(64), 0, stream, W, P, N, K);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(tiles), dim3(64), 0, stream, W, P, N, K, ldw ? ldw : K);
     AMT_LAUNCH_CHECK();
     return 0;
 }

@@ -98,7 +98,7 @@ int32_t amt_launch_attn_decode(const AttnDecodeParams& p, hipStream_t stream);
 
 // ---------------- decode-step skinny GEMM (decode_gemm.hip) ----------------
 // packed weight: tiles of 16(n) x 16(k): P[((nt*(K/16)+kt)*64 + lane)*4 + e] = W[nt*16+(lane&15)][kt*16+4*(lane>>4)+e]
-int32_t amt_launch_pack_weight(const float* W, float* P, int N, int K, hipStream_t stream);
+int32_t amt_launch_pack_weight(const float* W, float* P, int N, int K, hipStream_t stream, int ldw = 0);   // ldw: W's row stride (0 = K)
 struct DecodeGemmParams {
     const float* x; int ldx;    // [B][K] input rows (pre-LN sum when ln_w != null)
     const float* Wp;            // packed weight
