@@ -6,6 +6,7 @@
 #define AMT_WAVE 64
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));      // operand pairs of the packed fp32 ops (v_pk_fma_f32)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---- status convention of include/amt_hip.h: 0 ok, <0 bad argument, >0 hipError_t ----

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
     // [16 waves][4 r][64 lanes] partial tiles in a region of their own (behind the staged rows and the folded-FFN vectors): a wave stores its
     // partials as soon as its MFMAs are done, with no barrier in between (sharing the rows' region cost one: +0.6 % tokens/s without it)
     constexpr bool FFN = PRO == 2 || PRO == 5;       // folded-FFN prologues: per-column vectors handed over through LDS
-    float* red = smem + MT * LD + (PRO == 2 ? 2 * K : PRO == 5 ? 2 * K + 2 * p.K1 : 0);
+    float* red = smem + MT * LD + (PRO == 2 ? 2 * K + 2 * MT : PRO == 5 ? 2 * K + 2 * p.K1 : 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, m0 = blockIdx.y * MT;
     // column split: tiles below n_split multiply the first K1 input columns by Wp, the others all K by Wp2
@@ -169,12 +169,35 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
     const int row = m0 + 4 * (el >> 4) + er, n = nt * 16 + (el & 15);
     const bool live = tid < 256 && row < p.B && n < p.N;
     // ---- prologue math ----
-    if (FFN) {
-        // [ relu((raw - mu*g)*rstd + c) | LayerNorm(u) ], statistics over the u half (columns K1..K-1); PRO 5: up * silu(gate) for the ReLU
-        float* gs = smem + MT * LD;                 // [2][K]: g|gamma , c|beta  (PRO 5: then [2][K1]: the gate's g2 , c2)
+    if (PRO == 2) {
+        // folded FFN, [ relu((raw - mu*g)*rstd + c) | LayerNorm(u) ] with the statistics of the u half (columns K1..K-1): the rows are
+        // staged RAW, the wave leaves its row's (mu, rstd) and the per-column vectors in LDS, and the fix is applied to the A fragments
+        // when they are read for the MFMAs -- under the shadow of the weight tiles still in flight, every element exactly once (a wave
+        // owns its k range), and with ONE barrier instead of two (round 3: 1.56 us of a 6.5 us launch were this prologue)
+        float* gs = smem + MT * LD;                 // [2][K]: g|gamma , c|beta ; then [16][2]: mu, rstd per staged row
+        const float inv_n = 1.0f / (float)(K - K1);
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            const int i = (c * 64 + lane) * 4;
+            s += ((i >= K1 && (FULL || i < K)) ? 1.f : 0.f) * sum4(v[c]);
+        }
+        const float mean = wave_sum(s) * inv_n;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            const int i = (c * 64 + lane) * 4;
+            q += ((i >= K1 && (FULL || i < K)) ? 1.f : 0.f) * sq4(v[c], mean);
+        }
+        const float rstd = rsqrtf(wave_sum(q) * inv_n + p.eps);
+        gs[2 * K + 2 * wave + (lane & 1)] = (lane & 1) ? rstd : mean;      // (every lane stores one of the two words: no branch)
         st4(gs + gs_vec * K + gs_i, gs_val);        // unconditional (surplus threads repeat the last float4): a guarded
                                                     // store lets the compiler sink the load behind the weight loads
-        if (PRO == 5) st4(gs + 2 * K + gs2_vec * K1 + gs2_i, gs2_val);
+    } else if (PRO == 5) {
+        // [ up * silu(gate) | LayerNorm(u) ], both halves of the gated unit finished with the statistics of the u half (columns K1..K-1)
+        float* gs = smem + MT * LD;                 // [2][K]: g|gamma , c|beta , then [2][K1]: the gate's g2 , c2
+        st4(gs + gs_vec * K + gs_i, gs_val);
+        st4(gs + 2 * K + gs2_vec * K1 + gs2_i, gs2_val);
         const float inv_n = 1.0f / (float)(K - K1);
         float um[KCH];                              // 1 on the u half, 0 elsewhere (a multiply keeps the loops branch-free)
 #pragma unroll
@@ -196,10 +219,9 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
             const int i = (c * 64 + lane) * 4;
             const int ic = FULL ? i : min(i, K - 4);
             const float4 g = ld4(gs + ic), h = ld4(gs + K + ic);
-            // a 256-column chunk lies on one side of K1 in every shape the model builds (K1 = dim_feedforward, a multiple of 256
-            // at config 2; 256 at config 1): the side is then wave-uniform and each half takes its own short formula
-            if (256 * c + 256 <= K1) {               // raw half: relu((raw - mu*g)*rstd + c)
-                if (PRO == 5 && c < GCH) {           // up * silu(gate), both finished with the same row statistics
+            // K1 is a multiple of 256 (checked by the launcher): a 256-column chunk lies on one side of it and the side is wave-uniform
+            if (256 * c + 256 <= K1) {               // gated half: up * silu(gate)
+                if (c < GCH) {
                     const float4 g2 = ld4(gs + 2 * K + ic), h2 = ld4(gs + 2 * K + K1 + ic);
                     const float ux = (v[c].x - mean * g.x) * rstd + h.x, uy = (v[c].y - mean * g.y) * rstd + h.y;
                     const float uz = (v[c].z - mean * g.z) * rstd + h.z, uw = (v[c].w - mean * g.w) * rstd + h.w;
@@ -207,20 +229,10 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
                     const float tz = (gv[c].z - mean * g2.z) * rstd + h2.z, tw = (gv[c].w - mean * g2.w) * rstd + h2.w;
                     v[c].x = ux * (tx / (1.0f + __expf(-tx))); v[c].y = uy * (ty / (1.0f + __expf(-ty)));
                     v[c].z = uz * (tz / (1.0f + __expf(-tz))); v[c].w = uw * (tw / (1.0f + __expf(-tw)));
-                } else if (PRO != 5) {
-                v[c].x = fmaxf((v[c].x - mean * g.x) * rstd + h.x, 0.f); v[c].y = fmaxf((v[c].y - mean * g.y) * rstd + h.y, 0.f);
-                v[c].z = fmaxf((v[c].z - mean * g.z) * rstd + h.z, 0.f); v[c].w = fmaxf((v[c].w - mean * g.w) * rstd + h.w, 0.f);
                 }
-            } else if (256 * c >= K1 || PRO == 5) {  // LayerNorm half: (u - mu)*rstd*gamma + beta  (PRO 5: K1 is a multiple of 256)
+            } else {                                 // LayerNorm half: (u - mu)*rstd*gamma + beta
                 v[c].x = (v[c].x - mean) * rstd * g.x + h.x; v[c].y = (v[c].y - mean) * rstd * g.y + h.y;
                 v[c].z = (v[c].z - mean) * rstd * g.z + h.z; v[c].w = (v[c].w - mean) * rstd * g.w + h.w;
-            } else {                                 // K1 inside the chunk: one branch-free form for both (x*1.0f is exact)
-                const bool rawh = i < K1;
-                const float lo = rawh ? 0.f : -INFINITY;
-                v[c].x = fmaxf((v[c].x - (rawh ? mean * g.x : mean)) * rstd * (rawh ? 1.f : g.x) + h.x, lo);
-                v[c].y = fmaxf((v[c].y - (rawh ? mean * g.y : mean)) * rstd * (rawh ? 1.f : g.y) + h.y, lo);
-                v[c].z = fmaxf((v[c].z - (rawh ? mean * g.z : mean)) * rstd * (rawh ? 1.f : g.z) + h.z, lo);
-                v[c].w = fmaxf((v[c].w - (rawh ? mean * g.w : mean)) * rstd * (rawh ? 1.f : g.w) + h.w, lo);
             }
         }
     } else if (LN1) {
@@ -287,7 +299,16 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
             if (m0 + rr < p.B) p.xn[(size_t)(m0 + rr) * K + cb + c] = xs[rr * LD + cb + c];
     }
     // folded FFN: the LayerNorm half of the staged row is the residual of the low columns
-    if (FFN && live && !high) e_res = xs[(row - m0) * LD + K1 + n];
+    if (PRO == 5 && live && !high) e_res = xs[(row - m0) * LD + K1 + n];
+    const float* fgs = smem + MT * LD;              // PRO 2: the per-column vectors and the rows' statistics
+    float f_mu = 0.f, f_rs = 0.f;
+    if (PRO == 2) {
+        f_mu = fgs[2 * K + 2 * (lane & 15)]; f_rs = fgs[2 * K + 2 * (lane & 15) + 1];       // A-fragment row of this lane
+        if (live && !high) {
+            const float* sr = fgs + 2 * K + 2 * (row - m0);
+            e_res = fmaf(fmaf(xs[(row - m0) * LD + K1 + n], sr[1], -sr[0] * sr[1]), fgs[K1 + n], fgs[K + K1 + n]);      // (same spelling as the fragments')
+        }
+    }
 
     // ---- main: 4 MFMAs per k-tile ----
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -295,7 +316,27 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
 #pragma unroll
     for (int i = 0; i < KCH; ++i) {
         if (i < tpw && kt0 + i < kt_n) {
-            const float4 a0 = ld4(xa + i * 16);
+            float4 a0 = ld4(xa + i * 16);
+            if (PRO == 2) {
+                // the folded-FFN fix of this fragment.  It is VALU-bound (16 x 1536 elements per workgroup, every workgroup of the launch
+                // redoes them: with (a - mu*g)*rstd + c spelled as mul / sub / mul / add / max the fix cost 0.75 us of a 7.5 us launch),
+                // so each half is two fused multiply-adds per element, issued as packed pairs (v_pk_fma_f32), with mu*rstd per row:
+                //   raw half        relu(a*rstd + (c - mu*rstd*g))        LayerNorm half   (a*rstd - mu*rstd)*gamma + beta
+                // The side of K1 is wave-uniform (K1 % 16 == 0).
+                const int kc = (kt0 + i) * 16 + 4 * (lane >> 4);
+                const float4 g = ld4(fgs + kc), h = ld4(fgs + K + kc);
+                const f32x2 a_lo = {a0.x, a0.y}, a_hi = {a0.z, a0.w}, g_lo = {g.x, g.y}, g_hi = {g.z, g.w}, h_lo = {h.x, h.y}, h_hi = {h.z, h.w};
+                const f32x2 rs2 = {f_rs, f_rs}, nm2 = {-f_mu * f_rs, -f_mu * f_rs};
+                if ((kt0 + i) * 16 < K1) {
+                    const f32x2 t_lo = __builtin_elementwise_fma(a_lo, rs2, __builtin_elementwise_fma(nm2, g_lo, h_lo));
+                    const f32x2 t_hi = __builtin_elementwise_fma(a_hi, rs2, __builtin_elementwise_fma(nm2, g_hi, h_hi));
+                    a0 = make_float4(fmaxf(t_lo.x, 0.f), fmaxf(t_lo.y, 0.f), fmaxf(t_hi.x, 0.f), fmaxf(t_hi.y, 0.f));
+                } else {
+                    const f32x2 t_lo = __builtin_elementwise_fma(__builtin_elementwise_fma(a_lo, rs2, nm2), g_lo, h_lo);
+                    const f32x2 t_hi = __builtin_elementwise_fma(__builtin_elementwise_fma(a_hi, rs2, nm2), g_hi, h_hi);
+                    a0 = make_float4(t_lo.x, t_lo.y, t_hi.x, t_hi.y);
+                }
+            }
             const float4 w = wt[i];
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, w.y, acc, 0, 0, 0);
@@ -697,6 +738,10 @@ int32_t launch_wide(const DecodeGemmParams& p, hipStream_t stream) {
 
 template <int KCH, bool FULL>
 int32_t launch_variant(const DecodeGemmParams& p, size_t lds, hipStream_t stream) {
+#ifdef AMT_EXPERIMENT
+    // timing only (wrong values): what does the folded-FFN prologue cost?  exp_a = 1 launches the same product with the plain staging
+    if (p.pro == 1 && amt_tuning().exp_a == 1) return launch_one<KCH, FULL, 0>(p, lds, stream);
+#endif
     if (p.pro == 1) return launch_one<KCH, FULL, 2>(p, lds, stream);
     if (p.pro == 2) { if constexpr (FULL && KCH >= 2) return launch_one<KCH, FULL, 5>(p, lds, stream); }
     if (p.glu_gate) return launch_one<KCH, FULL, 3>(p, lds, stream);
@@ -782,7 +827,7 @@ int32_t amt_launch_decode_gemm(const DecodeGemmParams& p_in, hipStream_t stream)
         return ln ? launch_wide<4, 1, 4>(p, stream) : launch_wide<4, 0, 4>(p, stream);
     }
     // staged rows | folded-FFN vectors | the waves' partial tiles
-    const size_t lds = (size_t)MT * (p.K + XPAD) * sizeof(float) + (p.pro == 1 ? (size_t)2 * p.K * sizeof(float) : 0) +
+    const size_t lds = (size_t)MT * (p.K + XPAD) * sizeof(float) + (p.pro == 1 ? (size_t)(2 * p.K + 2 * MT) * sizeof(float) : 0) +
                        (p.pro == 2 ? (size_t)(2 * p.K + 2 * p.K1) * sizeof(float) : 0) + (size_t)NW * 256 * sizeof(float);
     int32_t rc;
     switch (p.K) {
