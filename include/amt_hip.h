@@ -325,7 +325,8 @@ int32_t amt_moe_ep_expert_fwd(const float* rows, const int32_t* recv_counts, int
  * (head-major: H, max_seq, hd), cross K (roped), V (head-major: H, S, hd), router w (null = plain GLU layer), router b, packed linear1, b, packed gate, b,
  * packed linear2, b (per expert, stacked, for a MoE layer), shared expert's six tensors (packed weights) or null; then, for the
  * lockstep step, the stacked forms: packed [gate of every expert (+ the shared one) | linear1 of every expert (+ shared)] as one matrix
- * and its bias, packed linear2 of every expert (+ shared) one after the other and their biases (both null for a plain GLU layer,
+ * -- with linear1 present its rows are interleaved in eights BEFORE packing (gate rows 8T..8T+7, then linear1 rows 8T..8T+7, T = 0, 1, ...:
+ * the product's epilogue writes linear1 * silu(gate) itself) -- and its bias in the stacked order [gate | linear1], packed linear2 of every expert (+ shared) one after the other and their biases (both null for a plain GLU layer,
  * whose linear2 is the per-layer entry above); last, for the lockstep step with norm1 folded through the cross-attention's query
  * projection (all four null: separate launches): packed [(Wq o gamma1) Wo | Wq o gamma1] (E x 2E), its bias (Wq o gamma1) bo,
  * g = rowsum(Wq o gamma1), c = Wq beta1 + bq  (Wo, bo: self-attention out-projection; Wq, bq: cross in_proj rows 0:E)); and, for

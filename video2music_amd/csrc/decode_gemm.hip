@@ -57,6 +57,18 @@ __device__ __forceinline__ float sq4(const float4 a, float m) {
 // predicates; PRO: 0 plain rows, 1 LayerNorm prologue, 2 folded-FFN prologue, 3 gated-linear-unit prologue, 4 two LayerNorms,
 // 5 folded gated FFN prologue (2 with a gate: up * silu(gate) in place of the ReLU).
 //
+
+// epilogue of a paired gate | up tile (DecodeGemmParams::glu_pair): lanes 0-7 of a 16-lane row hold the gate columns, lanes 8-15 the up
+// columns of the same 8 hidden columns; every lane gets up * silu(gate), the up lanes store it
+__device__ __forceinline__ float glu_pair_value(float val, int c) {
+    const float other = __shfl_xor(val, 8, 64);
+    const float g = c < 8 ? val : other, u = c < 8 ? other : val;
+    return u * (g / (1.0f + __expf(-g)));
+}
+__device__ __forceinline__ float act(float v, int relu) { return relu == 1 ? fmaxf(v, 0.f) : relu == 2 ? v / (1.0f + __expf(-v)) : v; }
+// column of the stacked bias that belongs to interleaved column n (N = stacked width)
+__device__ __forceinline__ int glu_pair_bias_col(int n, int N) { const int c = n & 15; return (c < 8 ? 0 : N / 2 - 8) + (n >> 4) * 8 + c; }
+
 // Everything the kernel reads from global memory is issued up front in ONE branch-free sequence: rows, prologue
 // vectors, weight tiles, epilogue operands (out-of-range lanes read a clamped address and discard the value).
 // Vector loads return in issue order and the compiler can only count them across straight-line code: with the
@@ -285,7 +297,7 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
     // being masked after the load: a select on a loaded value would be scheduled early and wait for the weights ----
     const float* bp = high ? p.bias2 : (p.bias ? p.bias + (size_t)grp * p.sel_b_stride : nullptr);      // (grp = blockIdx.z in a grouped launch)
     const bool has_b = live && bp != nullptr, has_r = !FFN && live && !high && p.mode == 0 && p.resid != nullptr;
-    const float e_bias = *(has_b ? bp + (high ? n - p.n_split : n) : p.zero);
+    const float e_bias = *(has_b ? bp + (high ? n - p.n_split : p.glu_pair ? glu_pair_bias_col(n, p.N) : n) : p.zero);
     float e_res = 0.f;
     if (!FFN) e_res = *(has_r ? p.resid + (size_t)row * p.ldr + n : p.zero);
     const int t = *(p.pos ? p.pos : reinterpret_cast<const int*>(p.zero));
@@ -370,7 +382,10 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
             val = (n & 1) ? val * c + other * sn : val * c - other * sn;
         }
     }
-    if (live) {
+    if (p.glu_pair) {                                // (outside `live`: the exchange takes every lane of the wave)
+        val = glu_pair_value(val, n & 15);
+        if (live && (n & 8)) p.y[(size_t)row * p.ldy + (n >> 4) * 8 + (n & 7)] = val;
+    } else if (live) {
         float* ybase = p.y + (size_t)zg * p.y_group_off;
         if (high) {
             p.y2[(size_t)row * p.ldy2 + (n - p.n_split)] = val;
@@ -378,7 +393,7 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(DecodeGemmParams p
             if (n < p.scale_cols) val *= p.scale;
             if (p.mode == 0) {
                 val += e_res;
-                if (p.relu) val = fmaxf(val, 0.f);
+                val = act(val, p.relu);
                 ybase[(size_t)row * p.ldy + n] = val;
             } else if (n < p.d) {
                 ybase[(size_t)row * p.ldy + n] = val;
@@ -507,7 +522,7 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_wide_kernel(DecodeGemmPar
     for (int q = 0; q < JN; ++q) {
         const int j = jg + 4 * q, n = (nt0 + j) * 16 + (el & 15);
         const bool live = j < NTW && row < p.B && n < p.N;
-        e_bias[q] = *((live && p.bias) ? p.bias + (size_t)zg * p.sel_b_stride + n : p.zero);
+        e_bias[q] = *((live && p.bias) ? p.bias + (size_t)zg * p.sel_b_stride + (p.glu_pair ? glu_pair_bias_col(n, p.N) : n) : p.zero);
         e_res[q] = *((live && p.resid) ? p.resid + (size_t)row * p.ldr + n : p.zero);
         if (PRO == 1 && p.xn && j < NTW && (nt0 + j) * 16 < K) {
             const int rr = e >> 4, c = e & 15;
@@ -546,10 +561,13 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_wide_kernel(DecodeGemmPar
 #pragma unroll
             for (int w = 0; w < NW; ++w) val += red[(j * NW + w) * 256 + e];
             val += e_bias[q];
-            if (row < p.B && n < p.N) {
+            if (p.glu_pair) {                        // (j < NTW is uniform per 256-thread group: whole waves take the exchange)
+                val = glu_pair_value(val, n & 15);
+                if (row < p.B && n < p.N && (n & 8)) p.y[(size_t)row * p.ldy + (n >> 4) * 8 + (n & 7)] = val;
+            } else if (row < p.B && n < p.N) {
                 if (n < p.scale_cols) val *= p.scale;
                 val += e_res[q];
-                if (p.relu) val = fmaxf(val, 0.f);
+                val = act(val, p.relu);
                 p.y[(size_t)zg * p.y_group_off + (size_t)row * p.ldy + n] = val;
             }
         }
@@ -632,7 +650,7 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_wide2_kernel(DecodeGemmPa
 #pragma unroll
     for (int q = 0; q < JN; ++q) {
         const int j = jg + 4 * q, n = (nt0 + j) * 16 + (el & 15);
-        e_bias[q] = *((j < NTW && n < p.N && p.bias) ? p.bias + n : p.zero);
+        e_bias[q] = *((j < NTW && n < p.N && p.bias) ? p.bias + (p.glu_pair ? glu_pair_bias_col(n, p.N) : n) : p.zero);
         if (PRO == 1 && p.xn && j < NTW && (nt0 + j) * 16 < K) {
             const int rr = e >> 4, c = e & 15;
 #pragma unroll
@@ -682,10 +700,13 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_wide2_kernel(DecodeGemmPa
 #pragma unroll
                 for (int w = 0; w < NW; ++w) val += red[(j * NW + w) * 256 + e];
                 val += e_bias[q];
-                if (row < p.B && n < p.N) {
+                if (p.glu_pair) {
+                    val = glu_pair_value(val, n & 15);
+                    if (row < p.B && n < p.N && (n & 8)) p.y[(size_t)row * p.ldy + (n >> 4) * 8 + (n & 7)] = val;
+                } else if (row < p.B && n < p.N) {
                     if (n < p.scale_cols) val *= p.scale;
                     if (p.resid) val += p.resid[(size_t)row * p.ldr + n];
-                    if (p.relu) val = fmaxf(val, 0.f);
+                    val = act(val, p.relu);
                     p.y[(size_t)row * p.ldy + n] = val;
                 }
             }
@@ -795,6 +816,8 @@ int32_t amt_launch_decode_gemm(const DecodeGemmParams& p_in, hipStream_t stream)
     AMT_CHECK_ARG(p.n_groups <= 1 || (!p.sel && p.n_split == 0 && !p.x2 && p.ldw == 0 && !p.resid && p.mode == 0 && p.n_groups <= 65535), "decode_gemm: a grouped launch takes plain single-source products");
     AMT_CHECK_ARG(!p.glu_gate || p.pro == 2 || (!p.ln_w && p.pro == 0 && (!p.x2 || (p.K1 % 256 == 0 && p.K % 256 == 0 && p.n_groups <= 1 && !p.glu_only))),
                   "decode_gemm: the gated prologue takes no LayerNorm, and a second source only behind whole 256-column chunks");
+    AMT_CHECK_ARG(!p.glu_pair || (p.N % 16 == 0 && p.mode == 0 && !p.resid && !p.rope && p.n_split == 0 && !p.sel && p.n_groups <= 1 && p.scale_cols == 0 &&
+                                  !p.relu && p.ldy >= p.N / 2), "decode_gemm: the paired gate | up epilogue takes a plain product of N %% 16 == 0 columns");
     AMT_CHECK_ARG(!p.rope || (p.pos && p.rope_dim > 0 && p.rope_dim % 2 == 0 && p.rope_cols % 2 == 0 && p.n_split == 0), "decode_gemm: bad rotary epilogue");
     if (p.pro == 2) {
         AMT_CHECK_ARG(p.x2 && p.glu_gate && p.fold_g && p.fold_c && p.fold_g2 && p.fold_c2 && p.ln_w && p.ln_b && !p.resid && p.K1 % 256 == 0 &&
@@ -810,9 +833,10 @@ int32_t amt_launch_decode_gemm(const DecodeGemmParams& p_in, hipStream_t stream)
     // the grouped down projections of a mixture layer (gated prologue): more workgroups than the chip holds at once with one
     // tile each, one round with two
     const int wide_grp = amt_tuning().wide_grouped;
-    if (wide_grp > 0 && p.n_groups > 1 && p.glu_gate && !p.ln_w && p.pro == 0 && !p.rope && !p.x2 && p.mode == 0 && p.ldw == 0 && !p.sel &&
+    if (wide_grp > 0 && p.n_groups > 1 && !p.ln_w && p.pro == 0 && !p.rope && !p.x2 && p.mode == 0 && p.ldw == 0 && !p.sel &&
         (p.K == 512 || p.K == 1024) && cdiv(p.N, 16) * cdiv(p.B, MT) * p.n_groups > 256) {
-        return p.K == 512 ? launch_wide<2, 3, 2>(p, stream) : launch_wide<4, 3, 2>(p, stream);
+        if (p.glu_gate) return p.K == 512 ? launch_wide<2, 3, 2>(p, stream) : launch_wide<4, 3, 2>(p, stream);
+        return p.K == 512 ? launch_wide<2, 0, 2>(p, stream) : launch_wide<4, 0, 2>(p, stream);      // (gated already: the producer's paired epilogue)
     }
     const int wide_ntw = amt_tuning().wide_ntw;
     if (wide_ntw > 0 && p.N >= 4096 && !p.x2 && p.n_split == 0 && !p.sel && p.n_groups <= 1 && p.mode == 0 && !p.rope && !p.glu_gate && p.pro == 0 &&

@@ -109,7 +109,7 @@ struct DecodeGemmParams {
     // epilogue
     int mode;                   // 0: y = acc+bias (+resid) (relu) ; 1: packed-QKV split into q / K-cache / V-cache
     const float* resid; int ldr;
-    int relu;
+    int relu;                   // 1: max(v, 0); 2: silu(v)
     float scale; int scale_cols;
     float* y; int ldy;
     // mode 1
@@ -142,6 +142,12 @@ struct DecodeGemmParams {
     // (GLUExpert.forward, moe.py:44-49), or silu(glu_gate) alone when glu_only (the Linear -> SiLU -> Linear experts of V1);
     // glu_gate has x's row stride and group offset
     const float* glu_gate; int glu_only;
+    // Gated-linear-unit EPILOGUE (glu_pair = 1; round 3): the packed weight is the stacked [gate | up] matrix with its rows interleaved in
+    // eights -- column tile T = [gate columns 8T..8T+7 | up columns 8T..8T+7] -- so a tile holds both halves of 8 hidden columns and
+    // the launch writes h = up * silu(gate) once per element: y[row*ldy + 8T + c], N/2 columns (N = the stacked width; `bias` keeps the
+    // stacked order [gate (N/2) | up (N/2)]).  The gated PROLOGUE above redoes that product in every workgroup of the consuming launch
+    // (16 x dff exp / rcp per workgroup on four SIMDs: ~2 us of an 8 us launch).  relu == 2: y = silu(acc + bias) (SiLU experts).
+    int glu_pair;
     // Rotary epilogue (rope != null): columns n < rope_cols are rotated as interleaved pairs (2i, 2i+1) by the angles of
     // position *pos in the table rope[pos][rope_dim] = (cos, sin) pairs (custom_transformer.py:1044-1053 as wired: the full
     // d_model vector, pair i by angle i); applied after the bias and before `scale`.  Column n uses table entry n % rope_dim.

@@ -21,7 +21,9 @@ enum { G_PR, G_PA, G_WKEY, G_CBIAS, G_ROPE, G_FNW, G_FNB, G_WOUT, G_BOUT, G_SLOT
 enum { L_SAW, L_SAB, L_SAOW, L_SAOB, L_N1W, L_N1B, L_CAW, L_CAB, L_CAOW, L_CAOB, L_N2W, L_N2B, L_N3W, L_N3B,
        L_KC, L_VC, L_KX, L_VX, L_GATEW, L_GATEB, L_W1, L_B1, L_WG, L_BG, L_W2, L_B2, L_SW1, L_SB1, L_SWG, L_SBG, L_SW2, L_SB2,
        // stacked forms for the lockstep step: [gate of every expert (+ shared) | linear1 of every expert (+ shared)] as ONE packed
-       // matrix and its bias; linear2 of every expert (+ shared) one after the other and their biases (null for a plain GLU layer)
+       // matrix -- when linear1 exists its rows INTERLEAVED in eights before packing (gate rows 8T..8T+7, then linear1 rows 8T..8T+7:
+       // DecodeGemmParams::glu_pair) -- and its bias in the stacked order; linear2 of every expert (+ shared) one after the other and
+       // their biases (null for a plain GLU layer)
        L_GU, L_GUB, L_W2S, L_B2S,
        // lockstep step, norm1 folded through the cross-attention's query projection (null: separate launches): packed
        // [(Wq o gamma) Wo | Wq o gamma] (E x 2E), its bias (Wq o gamma) bo, g = rowsum(Wq o gamma), c = Wq beta + bq
@@ -329,6 +331,7 @@ struct RowGemm {
     const float* rope = nullptr; int rope_cols = 0, rope_dim = 0; const int* pos = nullptr; float scale = 1.f; int scale_cols = 0;
     bool qkv = false; float* kc = nullptr; float* vc = nullptr; int H = 0, hd = 0, cap = 0;
     const float* gate = nullptr; bool gate_only = false;
+    int glu_pair = 0, relu = 0; int ldy = 0;          // paired gate | up epilogue (y = up * silu(gate), N / 2 columns) ; 2: y = silu(.)
     int groups = 1; size_t x_goff = 0, y_goff = 0, w_gstride = 0; int b_gstride = 0;
 };
 
@@ -336,7 +339,7 @@ int32_t row_gemm(const RowGemm& r, int B, hipStream_t s) {
     DecodeGemmParams g{};
     g.B = B; g.eps = 1e-5f; g.scale = r.scale; g.scale_cols = r.scale_cols;
     g.x = r.x ? r.x : r.gate; g.ldx = r.ldx ? r.ldx : r.K; g.Wp = r.wp; g.bias = r.b; g.N = r.N; g.K = r.K;
-    g.resid = r.resid; g.ldr = r.N; g.y = r.y; g.ldy = r.qkv ? r.N / 3 : r.N;
+    g.resid = r.resid; g.ldr = r.N; g.y = r.y; g.ldy = r.ldy ? r.ldy : r.qkv ? r.N / 3 : r.N; g.glu_pair = r.glu_pair; g.relu = r.relu;
     g.ln_w = r.ln_w; g.ln_b = r.ln_b; g.xn = r.xn; g.ln2_w = r.ln2_w; g.ln2_b = r.ln2_b;
     g.rope = r.rope; g.rope_cols = r.rope_cols; g.rope_dim = r.rope_dim; g.pos = r.pos;
     if (r.qkv) { g.mode = 1; g.kcache = r.kc; g.vcache = r.vc; g.H = r.H; g.hd = r.hd; g.cap = r.cap; g.d = r.N / 3; }
@@ -473,15 +476,19 @@ static int32_t v2_step_batch_impl(const void* const* tab, int32_t n_layers, int3
         // ---- feed-forward: [norm2 ->] gate projection; up projection; down projection with the gate applied in its prologue ----
         if (!(fuse_ln && pend_b)) { if ((rc = settle(xc))) return rc; }
         // gate and up projections of the block are ONE product over the stacked matrix [gate | linear1] (of every expert and the
-        // shared one in a mixture layer: their packed weights lie one after the other, which is the packed form of the stacked
-        // matrix), with norm2 in its prologue; the down projection(s) apply u * silu(g) in their prologue
+        // shared one in a mixture layer), with norm2 in its prologue.  The stacked matrix is packed with its rows interleaved in eights
+        // (tile T = gate columns 8T..8T+7 | up columns 8T..8T+7), so that launch's epilogue writes the hidden rows h = up * silu(gate)
+        // themselves, each element once (SiLU experts without an up projection: h = silu(.)); the down projection(s) are plain products.
+        // (Round 2 applied the gate in the down projections' prologue: every one of their 128 / 448 workgroups redid 16 x dff
+        //  exp / rcp on its four SIMDs, ~2 us of an 8 us launch.)
         const float* ffin;                                   // the normalised rows every projection of the block reads
         const bool has_up = P(L_W1) != nullptr;
         const int ng = L[L_GATEW] ? n_exp + (L[L_SWG] ? 1 : 0) : 1;
         const int Nall = ng * dff, Ngu = has_up ? 2 * Nall : Nall;
-        float* GU = ffs;                                     // [B][Ngu]: gate columns, then up columns
+        float* Hh = ffs;                                     // [B][Nall]: hidden rows of every expert (+ shared)
         {
-            RowGemm rg; rg.x = cur; rg.wp = P(L_GU); rg.b = P(L_GUB); rg.y = GU; rg.N = Ngu; rg.K = E;
+            RowGemm rg; rg.x = cur; rg.wp = P(L_GU); rg.b = P(L_GUB); rg.y = Hh; rg.N = Ngu; rg.K = E; rg.ldy = Nall;
+            if (has_up) rg.glu_pair = 1; else rg.relu = 2;
             if (pend_w) { rg.ln_w = pend_w; rg.ln_b = pend_b; rg.xn = xc; }
             if ((rc = CNT(row_gemm(rg, B, s)))) return rc;
             if (pend_w) { cur = xc; pend_w = pend_b = nullptr; }
@@ -489,21 +496,21 @@ static int32_t v2_step_batch_impl(const void* const* tab, int32_t n_layers, int3
         }
         if (!L[L_GATEW] && P(L_G3P) && fuse_ln && P(L_N3B) && has_up && l + 1 < n_layers) {
             // u = expert(x) + x AND the next layer's raw QKV product of norm3(u) in one launch (norm3 folded through that projection,
-            // the base model's G3): rows [up * silu(gate) | x], low columns through linear2 over the gated half (+ x), high columns
+            // the base model's G3): rows [h | x], low columns through linear2 over the gated half (+ x), high columns
             // through [(Wqkv' o gamma3) W2 | Wqkv' o gamma3]; the next self-attention finishes q / k / v with u's row statistics
             DecodeGemmParams d3{};
-            d3.B = B; d3.eps = 1e-5f; d3.scale = 1.f; d3.x = GU + Nall; d3.glu_gate = GU; d3.ldx = Ngu; d3.x2 = ffin; d3.ldx2 = E;
+            d3.B = B; d3.eps = 1e-5f; d3.scale = 1.f; d3.x = Hh; d3.ldx = Nall; d3.x2 = ffin; d3.ldx2 = E;
             d3.K1 = dff; d3.K = dff + E; d3.Wp = P(L_W2); d3.bias = P(L_B2); d3.resid = ffin; d3.ldr = E; d3.y = u; d3.ldy = E;
             d3.n_split = E; d3.N = 4 * E; d3.Wp2 = P(L_G3P); d3.bias2 = P(L_G3B); d3.y2 = qkv; d3.ldy2 = 3 * E;
             if ((rc = CNT(amt_launch_decode_gemm(d3, s)))) return rc;
             raw_qkv = true; raw_g = P(L_FKG); raw_c = P(L_FKC);
         } else if (!L[L_GATEW]) {
-            RowGemm rd; rd.x = has_up ? GU + Nall : nullptr; rd.gate = GU; rd.ldx = Ngu; rd.wp = P(L_W2); rd.b = P(L_B2); rd.resid = ffin;
+            RowGemm rd; rd.x = Hh; rd.ldx = Nall; rd.wp = P(L_W2); rd.b = P(L_B2); rd.resid = ffin;
             rd.y = u; rd.N = E; rd.K = dff;
             if ((rc = CNT(row_gemm(rd, B, s)))) return rc;             // u = expert(x) + x : the pre-norm sum of norm3
         } else {
             // the down projections of all experts and the shared one in ONE grouped launch (blockIdx.z = expert)
-            RowGemm rd; rd.x = has_up ? GU + Nall : nullptr; rd.gate = GU; rd.ldx = Ngu; rd.wp = P(L_W2S); rd.b = P(L_B2S); rd.y = Yall; rd.N = E; rd.K = dff;
+            RowGemm rd; rd.x = Hh; rd.ldx = Nall; rd.wp = P(L_W2S); rd.b = P(L_B2S); rd.y = Yall; rd.N = E; rd.K = dff;
             rd.groups = ng; rd.x_goff = (size_t)dff; rd.y_goff = BE; rd.w_gstride = (size_t)E * dff; rd.b_gstride = E;
             if ((rc = CNT(row_gemm(rd, B, s)))) return rc;
             const float* shared = L[L_SWG] ? Yall + (size_t)n_exp * BE : nullptr;

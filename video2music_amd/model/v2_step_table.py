@@ -111,14 +111,25 @@ def build_step_table(self, memory, S):
         ff = lyr.ff
 
         def stacked(mods, with_down):
-            """[gate of every module | linear1 of every module] as ONE packed matrix + bias (the lockstep step's single
-            gate/up product), and, for a mixture layer, linear2 of every module one after the other + biases."""
+            """[gate of every module | linear1 of every module] as ONE packed matrix (rows interleaved in eights when linear1 exists)
+            + bias (the lockstep step's single gate/up product), and, for a mixture layer, linear2 of every module one after the
+            other + biases."""
             parts = [expert_parts(e) for e in mods]
             srcs = [q[n] for n in ("gate", "linear1", "linear2") for q in parts if q[n] is not None]
 
             def build():
                 gu = [q["gate"] for q in parts] + [q["linear1"] for q in parts if q["linear1"] is not None]
-                out = [torch.cat([pack_now(l.weight) for l in gu]), torch.cat([l.bias.detach() for l in gu]).contiguous()]
+                if len(gu) == 2 * len(parts):
+                    # gate and linear1 rows interleaved in eights (column tile T of the product = gate columns 8T..8T+7 | linear1 columns
+                    # 8T..8T+7): the launch's epilogue then holds both halves of a hidden column and writes up * silu(gate) itself
+                    # (DecodeGemmParams::glu_pair, csrc/kernels.h); the bias keeps the stacked order
+                    g_rows = torch.cat([q["gate"].weight.detach() for q in parts])
+                    u_rows = torch.cat([q["linear1"].weight.detach() for q in parts])
+                    w = torch.stack([g_rows.view(-1, 8, g_rows.shape[1]), u_rows.view(-1, 8, u_rows.shape[1])], dim=1)
+                    wp = pack_now(w.reshape(-1, g_rows.shape[1]).contiguous())
+                else:
+                    wp = torch.cat([pack_now(l.weight) for l in gu])
+                out = [wp, torch.cat([l.bias.detach() for l in gu]).contiguous()]
                 if with_down:
                     out += [torch.cat([pack_now(q["linear2"].weight) for q in parts]),
                             torch.cat([q["linear2"].bias.detach() for q in parts]).contiguous()]
