@@ -282,6 +282,28 @@ def test_v2_at_bench_width_vs_reference_golden(golden):
         assert np.array_equal(toks[5].cpu().numpy(), g["g2"][0])
 
 
+@pytest.mark.parametrize("B,clips", [(24, (3, 20)), (40, (17, 39))])
+def test_lockstep_wide_gate_up_kernels_every_row_block(B, clips):
+    """At d_model 512 the stacked gate | up product of a mixture layer (7 x 2 x dff columns >= 4096) takes the wide skinny-GEMM kernels -- both
+    16-row blocks in one workgroup for 17 ... 32 clips, one row block per workgroup otherwise -- whose epilogue writes up * silu(gate) from
+    the interleaved tiles (round 3).  Clips of the first, second and third row block give the ids of `generate` on that clip alone."""
+    cfg = dict(CFG_V2, version_name="2.2", n_layers=2, num_heads=8, d_model=512, dim_feedforward=512, max_sequence_chord=40)
+    m = VideoMusicTransformer_V2(**cfg).eval()
+    shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.synthetic_state_dict(shapes, seed=5, recipe="feedback").items()})
+    m = m.cuda()
+    f = {k: v.cuda() for k, v in feats_t(synthetic.synthetic_features(B, seed=B)).items()}
+    pr = tuple(torch.tensor([v]) for v in (1, 1, 0))
+    T = 16
+    with torch.no_grad():
+        got = m.generate_batch(f["semantic"], f["key"], f["scene_offset"], f["motion"], f["emotion"], *pr, target_seq_length=T, beam=0, sampler="argmax")
+        assert got.shape == (B, T) and len(set(got[:, 1:].flatten().tolist())) >= 4
+        for c in clips:
+            one = m.generate(f["semantic"][c:c + 1], f["key"][c], f["scene_offset"][c:c + 1], f["motion"][c:c + 1], f["emotion"][c:c + 1],
+                             pr[0], pr[1], pr[2], target_seq_length=T, beam=0, sampler="argmax", decision="host")
+            assert torch.equal(one[0], got[c]), (c, one[0], got[c])
+
+
 @pytest.mark.parametrize("d,H,ff,nl", [(256, 4, 64, 4), (512, 4, 192, 3), (32, 1, 320, 3)])     # d_model 32: outside the step kernels' widths
 def test_v2_feed_forward_narrower_than_half_the_model_width(d, H, ff, nl):
     """2 * dim_feedforward < d_model: the stacked gate | up product of a GLU layer then has fewer column tiles than its LayerNorm
