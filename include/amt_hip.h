@@ -36,7 +36,8 @@
 #define AMT_HIP_H
 #include <stdint.h>
 
-#define AMT_ABI_VERSION 2    /* 2: argument structs for the step / skinny-GEMM calls, options in place of amt_debug_set_skip */
+#define AMT_ABI_VERSION 3    /* 2: argument structs for the step / skinny-GEMM calls, options in place of amt_debug_set_skip;
+                                3: the lockstep step's stacked gate | linear1 matrix is packed from rows interleaved in eights */
 
 #ifdef __cplusplus
 extern "C" {

@@ -115,7 +115,7 @@ _RESTYPES = {"amt_last_error": C.c_char_p, "amt_decode_step_bytes": C.c_int64, "
              "amt_v2_step_ws_floats": C.c_int64, "amt_v2_step_batch_ws_floats": C.c_int64, "amt_moe_ep_expert_scratch_floats": C.c_int64}
 _NO_STATUS = set(_RESTYPES) | {"amt_abi_version", "amt_v2_last_step_launches"}
 
-ABI_VERSION = 2          # AMT_ABI_VERSION of include/amt_hip.h these prototypes were written against
+ABI_VERSION = 3          # AMT_ABI_VERSION of include/amt_hip.h these prototypes were written against
 
 _lib = None
 
